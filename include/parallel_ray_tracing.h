@@ -1,0 +1,241 @@
+/*
+ * parallel_ray_tracing.h - C-ABI of libparallel_ray_tracing.so (MI355X / gfx950 build)
+ *
+ * Drop-in boundary for photon's ray-tracing core.  photon's Python driver loads the
+ * library with ctypes (python_codes/perform_ray_tracing_03.py:1888) and binds exactly
+ * one symbol, `start_ray_tracing` (argtypes at :1914-1921, restype None at :1925).
+ * The struct layouts below are the wire format of that call: they must agree byte for
+ * byte with the ctypes.Structure classes the reference builds at
+ * perform_ray_tracing_03.py:1651-1659 (scattering), :1708-1720 (source),
+ * :1751-1786 (element), :1838-1852 (camera), which in turn mirror
+ * cuda_codes/parallel_ray_tracing.h:17-191.  tests/test_abi.py checks sizeof/offsetof
+ * against fixtures captured from the reference's marshalling code.
+ *
+ * Everything is plain C: pointers, sizes, PODs.  No torch / HIP types appear in a
+ * signature (streams and device pointers travel as void*).
+ *
+ * Section 1  = the reference's ABI (what photon binds today).
+ * Section 2  = `photon_*` extension entry points (device-resident scene / volume /
+ *              image handles) that bench.py and the parity tests bind; the reference
+ *              has no counterpart, each cites the part of start_ray_tracing it factors out.
+ */
+#ifndef PHOTON_AMD_PARALLEL_RAY_TRACING_H_
+#define PHOTON_AMD_PARALLEL_RAY_TRACING_H_
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * Section 1: wire structs (x86-64 SysV natural alignment; sizes in bytes in brackets)
+ * ---------------------------------------------------------------------------------- */
+
+/* Mie-scattering lookup data [72].  Replaces cuda_codes/parallel_ray_tracing.h:17-33.
+ * scattering_irradiance is row-major [num_angles][num_diameters]; both pointers are
+ * NULL and the float fields NaN when scattering_type_str != "mie"
+ * (perform_ray_tracing_03.py:1685-1701). */
+typedef struct scattering_data_t {
+    float inverse_rotation_matrix[9];   /* @0  camera -> world */
+    float beam_propagation_vector[3];   /* @36 unit vector of the laser sheet */
+    float *scattering_angle;            /* @48 [num_angles], radians, uniform spacing */
+    float *scattering_irradiance;       /* @56 [num_angles*num_diameters] */
+    int num_angles;                     /* @64 */
+    int num_diameters;                  /* @68 */
+} scattering_data_t;
+
+/* Light-field sources = particles / dot-pattern points [64].
+ * Replaces cuda_codes/parallel_ray_tracing.h:36-60. */
+typedef struct lightfield_source_t {
+    int lightray_number_per_particle;   /* @0  */
+    int source_point_number;            /* @4  sources per launch chunk (10000 in photon) */
+    int *diameter_index;                /* @8  [num_particles] column of the Mie table */
+    double *radiance;                   /* @16 [num_particles] */
+    float *x;                           /* @24 [num_particles] microns, camera frame */
+    float *y;                           /* @32 */
+    float *z;                           /* @40 */
+    int num_particles;                  /* @48 */
+    float z_offset;                     /* @52 z_object - object_distance */
+    float object_distance;              /* @56 */
+} lightfield_source_t;
+
+/* [32] cuda_codes/parallel_ray_tracing.h:115-131 */
+typedef struct element_geometry_t {
+    float front_surface_radius;         /* @0  */
+    bool front_surface_spherical;       /* @4  */
+    float back_surface_radius;          /* @8  */
+    bool back_surface_spherical;        /* @12 */
+    float pitch;                        /* @16 clear aperture diameter */
+    double vertex_distance;             /* @24 centre thickness */
+} element_geometry_t;
+
+/* [24] cuda_codes/parallel_ray_tracing.h:134-141 */
+typedef struct element_properties_t {
+    float abbe_number;                  /* @0  NaN = no dispersion */
+    float absorbance_rate;              /* @4  */
+    double refractive_index;            /* @8  */
+    float thin_lens_focal_length;       /* @16 */
+    float transmission_ratio;           /* @20 */
+} element_properties_t;
+
+/* One optical element [120].  cuda_codes/parallel_ray_tracing.h:144-162.
+ * element_type: 'l' thick spherical lens, 't' thin lens, 'n' apparent image (no lens),
+ * anything else = aperture stop (parallel_ray_tracing.cu:416,507,868; :2143). */
+typedef struct element_data_t {
+    double axial_offset_distances[2];   /* @0  */
+    element_geometry_t element_geometry;/* @16 */
+    float element_number;               /* @48 */
+    element_properties_t element_properties; /* @56 */
+    char element_type;                  /* @80 */
+    float elements_coplanar;            /* @84 */
+    double rotation_angles[3];          /* @88 */
+    float z_inter_element_distance;     /* @112 */
+} element_data_t;
+
+/* Sensor description [112].  cuda_codes/parallel_ray_tracing.h:165-191. */
+typedef struct camera_design_t {
+    int pixel_bit_depth;                /* @0  */
+    float pixel_gain;                   /* @4  */
+    float pixel_pitch;                  /* @8  microns */
+    float x_camera_angle;               /* @12 */
+    float y_camera_angle;               /* @16 */
+    int x_pixel_number;                 /* @20 image width  W */
+    int y_pixel_number;                 /* @24 image height H */
+    float z_sensor;                     /* @28 */
+    float diffraction_diameter;         /* @32 pixels */
+    bool implement_diffraction;         /* @36 true: erf splat, false: 4-pixel splat */
+    float rotation_matrix[9];           /* @40 world -> camera */
+    float inverse_rotation_matrix[9];   /* @76 camera -> world */
+} camera_design_t;
+
+/*
+ * start_ray_tracing - render one sensor image.
+ * Replaces cuda_codes/parallel_ray_tracing.cu:3078-3775 (declared
+ * cuda_codes/parallel_ray_tracing.h:303-307).  Argument meaning is unchanged:
+ *   image_array        f32[H*W], row-major row*W+col, READ-MODIFY-WRITE (accumulates on
+ *                      the caller's contents, .cu:3309,3675)
+ *   element_center     f64[num_elements][3]; element_plane_parameters f64[num_elements][4]
+ *   ray_tracing_algorithm  1 euler, 2 rk4 (3 rk45 / 4 adams-bashforth: not built yet ->
+ *                      reported on stderr, image left untouched)
+ *   density_grad_filename  NRRD (type float, dim 3, raw little-endian), "" when unused
+ *   save_lightrays     writes <pos_path>/pos_%04d.bin, <dir_path>/dir_%04d.bin per chunk
+ * All pointers are borrowed for the duration of the call.  No error channel (void):
+ * on failure a message goes to stderr and image_array is left unmodified.
+ * Environment knobs (the ABI has no room for new arguments):
+ *   PHOTON_INTERP=linear|cubic   volume sampler (default linear = the reference's
+ *                                hard-coded interpolation_scheme 1, .cu:3330)
+ *   PHOTON_DEVICES=N             shard sources over the first N GPUs, RCCL-reduce image
+ *   PHOTON_VERBOSE=1             progress / timing on stdout
+ *   PHOTON_NOISE_SEED=u64        seed for the optional noise hooks (reference: time(NULL))
+ */
+void start_ray_tracing(float lens_pitch, float image_distance,
+                       scattering_data_t *scattering_data_p, char *scattering_type_str,
+                       lightfield_source_t *lightfield_source_p,
+                       int lightray_number_per_particle, float beam_wavelength,
+                       float aperture_f_number, int num_elements,
+                       double (*element_center)[3], element_data_t *element_data_p,
+                       double (*element_plane_parameters)[4], int *element_system_index,
+                       camera_design_t *camera_design_p, float *image_array,
+                       bool simulate_density_gradients, char *density_grad_filename,
+                       bool save_lightrays, char *lightray_position_save_path,
+                       char *lightray_direction_save_path, int num_lightrays_save,
+                       int ray_tracing_algorithm, bool add_pos_noise, float pos_noise_std,
+                       bool add_ngrad_noise, float ngrad_noise_std,
+                       float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
+                       int num_intermediate_positions_save);
+
+/* ------------------------------------------------------------------------------------
+ * Section 2: device-resident extension API (what bench.py / tests bind)
+ * Return value: 0 on success, non-zero HIP / argument error (message on stderr).
+ * ---------------------------------------------------------------------------------- */
+
+typedef struct photon_volume photon_volume_t;   /* refractive-index gradient volume in HBM */
+typedef struct photon_scene photon_scene_t;     /* sources, tables, optics, camera in HBM  */
+
+/* Host-visible description of a loaded volume (mirrors density_grad_params_t,
+ * cuda_codes/parallel_ray_tracing.h:213-252, minus the pointers). */
+typedef struct photon_volume_info_t {
+    float min_bound[3];
+    float max_bound[3];
+    int nx, ny, nz;
+    float grid_spacing[3];
+    float step_size;
+    float data_min;         /* min over the volume of n-1 */
+    int interpolation;      /* 1 trilinear, 2 tricubic B-spline */
+} photon_volume_info_t;
+
+/* Per-trace counters (filled from device atomics; for roofline accounting). */
+typedef struct photon_trace_stats_t {
+    uint64_t rays_launched;
+    uint64_t rays_on_sensor;        /* rays that reached the splat stage inside the sensor */
+    uint64_t rk_iterations;         /* completed integrator iterations, summed over rays */
+    uint64_t volume_samples;        /* sampler invocations, summed over rays */
+    uint64_t sensor_taps;           /* atomic adds issued */
+    float march_ms;                 /* HIP-event time of the volume-march kernel(s) */
+    float total_ms;                 /* HIP-event time of the whole trace */
+} photon_trace_stats_t;
+
+/* Select the GPU this thread's subsequent photon_* calls use (hipSetDevice). */
+int photon_set_device(int device);
+
+/* glibc-compatible lens-sample table, factored out of parallel_ray_tracing.cu:3216-3243
+ * (srand(10); r1[k]=rand()/RAND_MAX; r2[k]=rand()/RAND_MAX, interleaved).  Host arrays. */
+int photon_rand_table(int n, float *r1, float *r2);
+
+/* NRRD load + n-1 / grad(n) volume build (+ B-spline prefilter when interpolation==2).
+ * Replaces readDatafromFile/loadNRRD/setData/Host_Init,
+ * cuda_codes/trace_rays_through_density_gradients.h:1612-2105. */
+int photon_volume_load_nrrd(const char *path, int interpolation, photon_volume_t **out);
+/* Same, from a density field already on the host (x fastest), for synthetic volumes.
+ * origin is the NRRD "space origin" BEFORE the reference's -750e3 z shift (.h:1704). */
+int photon_volume_from_density(const float *rho, int nx, int ny, int nz,
+                               const double spacing[3], const double origin[3],
+                               int interpolation, photon_volume_t **out);
+int photon_volume_info(const photon_volume_t *vol, photon_volume_info_t *info);
+/* Copy the float4 texels (grad x,y,z, n-1) -- or the B-spline coefficients when
+ * interpolation==2 and coefficients!=0 -- back to the host: f32[nz*ny*nx*4]. */
+int photon_volume_download(const photon_volume_t *vol, int coefficients, float *out);
+/* Sample at n unnormalised texel coordinates (the argument of tex3D / cubicTex3D,
+ * trace_rays_through_density_gradients.h:1052,1216): coords f32[n][3] -> out f32[n][4].
+ * Host arrays; used by the sampler parity tests. */
+int photon_volume_sample(const photon_volume_t *vol, int n, const float *coords, float *out);
+void photon_volume_free(photon_volume_t *vol);
+
+/* Upload everything start_ray_tracing copies to the device before its launch loop
+ * (parallel_ray_tracing.cu:3132-3314): same arguments, same meaning. */
+int photon_scene_create(float lens_pitch, float image_distance,
+                        const scattering_data_t *scattering_data_p,
+                        const char *scattering_type_str,
+                        const lightfield_source_t *lightfield_source_p,
+                        int lightray_number_per_particle, float beam_wavelength,
+                        float aperture_f_number, int num_elements,
+                        const double (*element_center)[3], const element_data_t *element_data_p,
+                        const double (*element_plane_parameters)[4],
+                        const int *element_system_index,
+                        const camera_design_t *camera_design_p, float ray_cone_pitch_ratio,
+                        photon_scene_t **out);
+void photon_scene_free(photon_scene_t *scene);
+
+/* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
+ * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.
+ * vol may be NULL (= simulate_density_gradients false).  stream: hipStream_t as void*
+ * (NULL = default stream).  Asynchronous unless stats != NULL (stats forces a sync). */
+int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_tracing_algorithm,
+                 int64_t src_begin, int64_t src_end, float *d_image, void *stream,
+                 photon_trace_stats_t *stats);
+
+/* March-only entry point for parity tests: n rays (host arrays pos/dir f32[n][3], world
+ * frame) through trace_rays_through_density_gradients (.h:1455-1544); results in place,
+ * steps (optional) receives the per-ray completed iteration count. */
+int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorithm, int n,
+                             float *pos, float *dir, int *steps);
+
+/* Library / build identification string (static storage). */
+const char *photon_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHOTON_AMD_PARALLEL_RAY_TRACING_H_ */
