@@ -1,0 +1,342 @@
+// device_optics.hpp - per-ray optics on the device: light-field ray generation with Mie lookup,
+// lens / aperture propagation, sensor intersection and the two splat models.
+//
+// Replaces these device functions of cuda_codes/parallel_ray_tracing.cu:
+//   generate_lightfield_angular_data   :71-237     ray_sphere_intersection        :239-343
+//   measure_distance_to_optical_axis   :345-380    propagate_rays_through_single_element :383-1011
+//   propagate_rays_through_optical_system :1274-1381
+//   intersect_sensor_02 :1383-1543   create_apparent_image :1545-1733   intersect_sensor :1735-1895
+// Float/double placement follows the reference expression by expression; elementary functions
+// come from include/photon_det_math.h (bit-reproducible, see that header).
+#pragma once
+#include "../../include/parallel_ray_tracing.h"
+#include "../../include/photon_det_math.h"
+#include "device_vec.hpp"
+
+namespace photon {
+
+constexpr int kMaxElements = 5;         // MAX_CURRENT_ELEMENTS (.cu:38)
+
+// Everything start_ray_tracing uploads before its launch loop (.cu:3132-3314), by value.
+struct SceneDev {
+    float lens_pitch, image_distance, beam_wavelength, f_number, ratio;
+    int scattering_type;                // 1 = Mie table, 0 = diffuse
+    int rays_per_source;
+    const float *sx, *sy, *sz;          // light-field sources, SoA
+    const double *sradiance;
+    const int *sdia;
+    int num_sources;
+    float z_offset, object_distance;
+    float mie_inv_rot[9];
+    float beam[3];
+    const float *mie_angle;             // [num_angles]
+    const float *mie_irr;               // [num_angles][num_diameters]
+    int num_angles, num_diameters;
+    const float *r1, *r2;               // lens-sample table, shared by all sources (.cu:2006)
+    int num_elements;
+    element_data_t elems[kMaxElements];
+    float centers[kMaxElements][3];
+    float planes[kMaxElements][4];
+    int sys_index[kMaxElements];
+    camera_design_t cam;
+};
+
+struct Ray {                            // light_ray_data_t
+    f3 pos, dir;
+    float wavelength;
+    double radiance;
+};
+
+__device__ __forceinline__ void kill(Ray &r) {
+    r.pos = nan3();
+    r.dir = nan3();
+    r.wavelength = nanf32();
+    r.radiance = (double)nanf32();
+}
+
+// generate_lightfield_angular_data (.cu:71-237)
+__device__ __forceinline__ Ray generate_ray(const SceneDev &sc, int source, int local_ray) {
+    const float x_current = sc.sx[source], y_current = sc.sy[source], z_current = sc.sz[source];
+    const double src_radiance = sc.sradiance[source];
+    float x_lens, y_lens;
+    if (sc.rays_per_source == 1) {
+        x_lens = 0.0f; y_lens = 0.0f;
+    } else {                            // .cu:123-124: the whole product is evaluated in double
+        const float r1 = sc.r1[local_ray], r2 = sc.r2[local_ray];
+        double s, c;
+        photon_det_sincos(2 * M_PI * r2, &s, &c);
+        x_lens = (float)(sc.ratio * 1.0 * sc.lens_pitch * r1 * c);
+        y_lens = (float)(sc.ratio * 1.0 * sc.lens_pitch * r1 * s);
+    }
+    const float theta = photon_det_atanf(-(x_lens - x_current) / (sc.image_distance - z_current));
+    const float phi = photon_det_atanf(-(y_lens - y_current) / (sc.image_distance - z_current));
+    const f3 d0 = normalize(mk3(photon_det_tanf(theta), photon_det_tanf(phi), -1.0f));
+    double irradiance_current;
+    if (sc.scattering_type) {
+        const float del = sc.mie_angle[1] - sc.mie_angle[0];
+        const f3 beam = mk3(sc.beam[0], sc.beam[1], sc.beam[2]);
+        f3 d = normalize(matvec(sc.mie_inv_rot, d0));
+        const float dp = beam.x * d.x + beam.y * d.y + beam.z * d.z;
+        const float deg = (float)(photon_det_acosf(dp) * 180.0 / M_PI);     // angleBetween -> degrees
+        const float ray_angle = (float)(deg * M_PI / 180.0);                // .cu:184
+        const float angle = (ray_angle - sc.mie_angle[0]) / del;
+        const int angle_l = isnan(angle) ? 0 : (int)angle;
+        const int angle_u = angle_l + 1;
+        // rows clamped into the table: the reference reads one row past the end when the angle
+        // lands on the last row (.cu:194-198)
+        const int rl = clampi(angle_l, 0, sc.num_angles - 1), ru = clampi(angle_u, 0, sc.num_angles - 1);
+        const int col = clampi(sc.sdia[source], 0, sc.num_diameters - 1);
+        const float il = sc.mie_irr[rl * sc.num_diameters + col];
+        const float iu = sc.mie_irr[ru * sc.num_diameters + col];
+        const float irr = il + (angle - angle_l) / (angle_u - angle_l) * (iu - il);
+        irradiance_current = irr * src_radiance;
+    } else {
+        irradiance_current = src_radiance;
+    }
+    Ray r;
+    r.pos = mk3(x_current, y_current, z_current);
+    r.dir = d0;
+    r.wavelength = sc.beam_wavelength;
+    r.radiance = 1 / (sc.f_number * sc.f_number) * irradiance_current;      // .cu:233
+    return r;
+}
+
+// ray_sphere_intersection (.cu:239-343).  The f32 cancellation in gamma is reproduced, not fixed.
+__device__ __forceinline__ f3 ray_sphere_intersection(f3 pos_c, float R, f3 dir_i, f3 pos_i) {
+    const float alpha = dot(dir_i, dir_i);
+    const float beta = 2 * dot(dir_i, (pos_i - pos_c));
+    const float gamma = dot(pos_i - pos_c, pos_i - pos_c) - R * R;
+    const float sq = (float)(beta * beta - 4.0 * alpha * gamma);
+    if (sq < 0.0) return nan3();
+    const float t1 = (float)((-beta + sqrtf(sq)) / (2.0 * alpha));
+    const float t2 = (float)((-beta - sqrtf(sq)) / (2.0 * alpha));
+    // front and back surface make the same choice (.cu:298-336): R>0 -> smaller root
+    const float t = (R > 0) ? (t1 <= t2 ? t1 : t2) : (t1 >= t2 ? t1 : t2);
+    return pos_i + dir_i * t;
+}
+
+// measure_distance_to_optical_axis (.cu:345-380)
+__device__ __forceinline__ float axis_distance(f3 pos_i, f3 pos_0, const float *plane) {
+    const float a = plane[0], b = plane[1], c = plane[2];
+    const float tmin = dot(mk3(a, b, c), pos_i - pos_0) / (a * a + b * b + c * c);
+    const f3 p = pos_0 + mk3(a, b, c) * tmin;
+    return sqrtf(dot(pos_i - p, pos_i - p));
+}
+
+// propagate_rays_through_single_element (.cu:383-1011)
+__device__ __forceinline__ Ray single_element(const element_data_t &e, f3 center, const float *plane, Ray ray) {
+    const char type = e.element_type;
+    f3 dir = ray.dir, src = ray.pos;
+    const float wavelength = ray.wavelength;
+    double radiance = ray.radiance;
+    const float a = plane[0], b = plane[1], c = plane[2], d = plane[3];
+    const float pitch = e.element_geometry.pitch;
+    const double vertex_distance = e.element_geometry.vertex_distance;
+    if (type == 't') {                                                  // thin lens :416-503
+        const float focal = e.element_properties.thin_lens_focal_length;
+        const float t = -(dot(mk3(a, b, c), src) + d) / dot(mk3(a, b, c), dir);
+        const f3 hit = src + dir * t;
+        const float dist = axis_distance(hit, center, plane);
+        if (dist > pitch / 2.0) { kill(ray); return ray; }
+        src = hit;
+        dir = -(src - center) / focal + dir;
+        dir = normalize(dir);
+    } else if (type == 'l') {                                           // thick lens :507-864
+        const float Rf = e.element_geometry.front_surface_radius;
+        const float Rb = e.element_geometry.back_surface_radius;
+        const double n_lens = e.element_properties.refractive_index;
+        const float abbe = e.element_properties.abbe_number;
+        const float transmission = e.element_properties.transmission_ratio;
+        const float absorbance = e.element_properties.absorbance_rate;
+        const float nmag = sqrtf(a * a + b * b + c * c);
+        float ds = (float)(+vertex_distance / 2.0 - Rf);
+        const f3 c_front = center + mk3(a, b, c) * ds / nmag;
+        f3 hit = ray_sphere_intersection(c_front, Rf, dir, src);
+        float dist = axis_distance(hit, center, plane);
+        if (dist > pitch / 2.0) { kill(ray); return ray; }
+        f3 normal = normalize(hit - c_front);
+        float eta;
+        const float lambda_D = 589.3, lambda_F = 486.1, lambda_C = 656.3;
+        if (!isnan(abbe)) {                                             // Cauchy dispersion :622-636
+            eta = (float)(1.0 / (n_lens + (1. / (wavelength * wavelength) - 1 / (lambda_D * lambda_D)) *
+                                              ((n_lens - 1) / (abbe * (1 / (lambda_F * lambda_F) -
+                                                                       1 / (lambda_C * lambda_C))))));
+        } else {
+            eta = (float)(1.0 / n_lens);
+        }
+        float cosi = -dot(dir, normal);
+        float radicand = (float)(1.0 - (eta * eta) * (1.0 - cosi * cosi));
+        if (radicand < 0.0) { kill(ray); return ray; }                  // total internal reflection
+        dir = dir * eta + (eta * cosi - sqrtf(radicand)) * normal;
+        dir = normalize(dir);
+        src = hit;
+        ds = (float)(-vertex_distance / 2 - Rb);
+        const f3 c_back = center + mk3(a, b, c) * ds / nmag;
+        hit = ray_sphere_intersection(c_back, Rb, dir, src);
+        dist = axis_distance(hit, center, plane);
+        if (dist > pitch / 2.0) { kill(ray); return ray; }
+        normal = normalize(-(hit - c_back));
+        if (!isnan(abbe)) {
+            eta = (float)(n_lens + (1.0 / (wavelength * wavelength) - 1.0 / (lambda_D * lambda_D)) *
+                                       ((n_lens - 1) / (abbe * (1 / (lambda_F * lambda_F) -
+                                                                1 / (lambda_C * lambda_C)))));
+        } else {
+            eta = (float)n_lens;
+        }
+        cosi = -dot(dir, normal);
+        radicand = (float)(1.0 - (eta * eta) * (1.0 - cosi * cosi));
+        if (radicand < 0.0) { kill(ray); return ray; }
+        dir = eta * dir + (eta * cosi - sqrtf(radicand)) * normal;
+        dir = normalize(dir);
+        if (absorbance != 0) {
+            const float dist_in = sqrtf(dot(hit - src, hit - src));
+            radiance = (1.0 - absorbance) * radiance * dist_in;
+        } else {
+            radiance = transmission * radiance;
+        }
+        src = hit;
+    } else {                                                            // aperture stop :868-992
+        const float nmag = sqrtf(a * a + b * b + c * c);
+        float ds = (float)(-vertex_distance / 2.0);
+        float d_temp = d - ds * nmag;
+        float t = -(dot(mk3(a, b, c), src) + d_temp) / dot(mk3(a, b, c), dir);
+        f3 hit = src + dir * t;
+        float dist = axis_distance(hit, center, plane);
+        if (dist > pitch / 2.0) { kill(ray); return ray; }
+        ds = (float)(+vertex_distance / 2);
+        d_temp = d - ds * nmag;
+        t = -(dot(mk3(a, b, c), src) + d_temp) / dot(mk3(a, b, c), dir);
+        hit = src + dir * t;
+        dist = axis_distance(hit, center, plane);
+        if (dist > pitch / 2.0) { kill(ray); return ray; }
+        src = hit;
+    }
+    ray.dir = dir; ray.pos = src; ray.wavelength = wavelength; ray.radiance = radiance;
+    return ray;
+}
+
+// propagate_rays_through_optical_system (.cu:1274-1381): sequential groups; a group with exactly
+// one member is propagated through element 0 (.cu:1331-1333); larger groups reach the
+// reference's empty multi-element stub and leave the ray unchanged.
+__device__ __forceinline__ Ray optical_system(const SceneDev &sc, Ray ray) {
+    int seq = 0;
+    for (int k = 0; k < sc.num_elements; k++)
+        if (seq <= sc.sys_index[k]) seq = sc.sys_index[k];
+    for (int idx = 0; idx < seq; idx++) {
+        int count = 0;
+        for (int k = 0; k < sc.num_elements; k++)
+            if (seq - sc.sys_index[k] == idx) count++;
+        if (count == 1)
+            ray = single_element(sc.elems[0], mk3(sc.centers[0][0], sc.centers[0][1], sc.centers[0][2]),
+                                 sc.planes[0], ray);
+    }
+    return ray;
+}
+
+// Gaussian-spot splat: I0*pi/32 * d_erf(col) * d_erf(row) over the pixels within
+// render_fraction*D of the centroid (.cu:1477-1540 / :1660-1730).  The x and y erf differences
+// depend on col resp. row only, so they are evaluated once per column / per (column,row) -- the
+// products are the reference's, term for term.  One global_atomic_add_f32 per rendered pixel.
+__device__ __forceinline__ int erf_splat(float *image, int W, int H, float d_x, float d_y, double radiance,
+                                         f3 dir, float D, float render_fraction) {
+    const double pi = 3.141592653589793;
+    const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
+    const float ca = photon_det_cosf(alpha);
+    const double cos4 = ca * ca * ca * ca;
+    const float X = d_x - 0.5, Y = d_y - 0.5;
+    const float I0 = (float)(radiance * cos4 * 8.0 / pi);
+    const float sqrt8 = sqrtf(8.0f);
+    const int c0 = (int)floorf(X - render_fraction * D), c1 = (int)ceilf(X + render_fraction * D);
+    const int r0 = (int)floorf(Y - render_fraction * D), r1 = (int)ceilf(Y + render_fraction * D);
+    const double scale = I0 * pi / 32.0;
+    int taps = 0;
+    for (int col = c0; col <= c1; col++) {
+        if (col < 0 || col > W - 1) continue;
+        const double ex = erf(sqrt8 * (col - X - 0.5) / D) - erf(sqrt8 * (col - X + 0.5) / D);
+        const double sx = scale * ex;
+        for (int row = r0; row <= r1; row++) {
+            const float rad = sqrtf((col - X) * (col - X) + (row - Y) * (row - Y));
+            if (!(row >= 0 && row <= H - 1 && rad <= render_fraction * D)) continue;
+            const double ey = erf(sqrt8 * (row - Y - 0.5) / D) - erf(sqrt8 * (row - Y + 0.5) / D);
+            const float inc = (float)(sx * ey);
+            atomicAdd(&image[(size_t)row * W + col], inc);
+            taps++;
+        }
+    }
+    return taps;
+}
+
+struct Pixel { float d_x, d_y; bool inside; };
+
+__device__ __forceinline__ f3 sensor_hit(const Ray &ray, float a, float b, float c, float d, f3 dir) {
+    const float t = -(dot(mk3(a, b, c), ray.pos) + d) / dot(mk3(a, b, c), dir);
+    return ray.pos + dir * t;
+}
+
+// intersect_sensor_02 (.cu:1383-1543): erf splat, x axis flipped.  Returns final position.
+__device__ __forceinline__ f3 sensor_diffraction(float *image, const Ray &ray, const camera_design_t &cam, int &taps) {
+    const f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
+    const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
+    const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
+    const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;
+    const float d_y = (hit.y - p1y) / cam.pixel_pitch;
+    if (d_x >= cam.x_pixel_number || d_y >= cam.y_pixel_number || d_x < 0 || d_y < 0) return nan3();
+    taps += erf_splat(image, cam.x_pixel_number, cam.y_pixel_number, d_x, d_y, ray.radiance, ray.dir,
+                      cam.diffraction_diameter, 0.75f);
+    return hit;
+}
+
+// create_apparent_image (.cu:1545-1733): back-project to the object plane, scale by the
+// thin-lens magnification, splat with render_fraction 1.
+__device__ __forceinline__ f3 apparent_image(float *image, const Ray &ray, const camera_design_t &cam,
+                                             float z_object, float z_offset, const element_data_t &e, int &taps) {
+    const f3 dir = -ray.dir;
+    f3 hit = sensor_hit(ray, 0.0f, 0.0f, -1.0f, z_object, dir);
+    const float focal = e.element_properties.thin_lens_focal_length;
+    const float M = focal / (z_object - z_offset - focal);
+    hit.x = -hit.x * M;
+    hit.y = -hit.y * M;
+    const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
+    const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
+    const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;
+    const float d_y = (hit.y - p1y) / cam.pixel_pitch;
+    if (d_x >= cam.x_pixel_number || d_y >= cam.y_pixel_number || d_x < 0 || d_y < 0) return nan3();
+    taps += erf_splat(image, cam.x_pixel_number, cam.y_pixel_number, d_x, d_y, ray.radiance, dir,
+                      cam.diffraction_diameter, 1.0f);
+    return hit;
+}
+
+// intersect_sensor + 4-pixel area-weighted splat (.cu:1735-1895, :2199-2234)
+__device__ __forceinline__ f3 sensor_bilinear(float *image, const Ray &ray, const camera_design_t &cam, int &taps) {
+    const f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
+    const f3 dir = ray.dir;
+    const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
+    const float ca = photon_det_cosf(alpha);
+    const double cos4 = ca * ca * ca * ca;
+    const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
+    const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
+    const float d_x = (hit.x - p1x) / cam.pixel_pitch;
+    const float d_y = (hit.y - p1y) / cam.pixel_pitch;
+    if (d_x >= cam.x_pixel_number || d_y >= cam.y_pixel_number || d_x < 0 || d_y < 0) return nan3();
+    const float d_y_lower = d_y - 0.5, d_x_lower = d_x - 0.5;
+    const double d_ii_ul = ceilf(d_y_lower) - d_y_lower;
+    const double d_jj_ul = ceilf(d_x_lower) - d_x_lower;
+    const double w[4] = {d_ii_ul * d_jj_ul, d_ii_ul * (1 - d_jj_ul), (1 - d_ii_ul) * d_jj_ul,
+                         (1 - d_ii_ul) * (1 - d_jj_ul)};
+    const int ii_ul = (int)(ceilf(d_y_lower) - 1), jj_ul = (int)(ceilf(d_x_lower) - 1);
+    const int ii[4] = {ii_ul, ii_ul, ii_ul + 1, ii_ul + 1};
+    const int jj[4] = {jj_ul, jj_ul + 1, jj_ul, jj_ul + 1};
+    const int W = cam.x_pixel_number, H = cam.y_pixel_number;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (ii[k] < 0 || ii[k] >= H || jj[k] < 0 || jj[k] >= W) continue;
+        const long idx = (long)(ii[k] - 1) * W + jj[k] - 1;        // the reference's index (.cu:2228)
+        if (idx < 0) continue;                                      // would write before the image
+        const double inc = w[k] * ray.radiance * cos4;
+        atomicAdd(&image[idx], (float)inc);
+        taps++;
+    }
+    return hit;
+}
+
+}  // namespace photon

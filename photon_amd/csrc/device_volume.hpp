@@ -1,0 +1,317 @@
+// device_volume.hpp - refractive-index-gradient volume: samplers and ray integrators (device).
+//
+// Replaces, for gfx950, the CUDA texture path of the reference:
+//   tex3D(tex_data, ...) trilinear fetch      trace_rays_through_density_gradients.h:77,1052,1612-1646
+//   cubicTex3D(coeffs3D, ...) tricubic fetch  CubicInterpolationCUDA/code/internal/cubicTex3D_kernel.cu:48-81
+//   IntersectWithVolume / lookup / bounds     trace_rays_through_density_gradients.h:100-277
+//   euler / rk4                               trace_rays_through_density_gradients.h:743-1291
+// There is no texture unit on the path: texels are float4 in HBM (x fastest), addressed and
+// filtered in software with a fixed operation order.
+#pragma once
+#include <float.h>
+#include "device_vec.hpp"
+
+namespace photon {
+
+// density_grad_params_t (cuda_codes/parallel_ray_tracing.h:213-252) as the kernels see it
+struct VolumeDev {
+    f3 min_bound, max_bound;
+    int nx, ny, nz;
+    float step_size;
+    float data_min;
+    int interpolation;          // 1 trilinear, 2 tricubic
+    const f4 *texels;           // grad n (xyz), n-1 (w)   [nz][ny][nx]
+    const f4 *coeffs;           // B-spline coefficients    [nz][ny][nx] (interpolation == 2)
+};
+
+struct MarchCount { int iterations; int samples; };
+
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
+__device__ __forceinline__ f4 lerp4(f4 a, f4 b, float t) {
+    return f4{lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)};
+}
+__device__ __forceinline__ f4 ldtexel(const f4 *p) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);      // one global_load_dwordx4
+    return f4{v.x, v.y, v.z, v.w};
+}
+
+// Trilinear fetch at unnormalised coordinates, clamp addressing: sample point x-0.5, texels
+// floor and floor+1 (CUDA "linear filtering" semantics, exact f32 weights).
+__device__ __forceinline__ f4 tex3d_linear(const VolumeDev &v, float x, float y, float z) {
+    const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
+    const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
+    const float a = xb - fi, b = yb - fj, c = zb - fk;
+    const int i0 = clampi((int)fi, 0, v.nx - 1), i1 = clampi((int)fi + 1, 0, v.nx - 1);
+    const int j0 = clampi((int)fj, 0, v.ny - 1), j1 = clampi((int)fj + 1, 0, v.ny - 1);
+    const int k0 = clampi((int)fk, 0, v.nz - 1), k1 = clampi((int)fk + 1, 0, v.nz - 1);
+    const size_t W = v.nx, WH = (size_t)v.nx * v.ny;
+    const f4 *t = v.texels;
+    const f4 v000 = ldtexel(t + k0 * WH + j0 * W + i0), v100 = ldtexel(t + k0 * WH + j0 * W + i1);
+    const f4 v010 = ldtexel(t + k0 * WH + j1 * W + i0), v110 = ldtexel(t + k0 * WH + j1 * W + i1);
+    const f4 v001 = ldtexel(t + k1 * WH + j0 * W + i0), v101 = ldtexel(t + k1 * WH + j0 * W + i1);
+    const f4 v011 = ldtexel(t + k1 * WH + j1 * W + i0), v111 = ldtexel(t + k1 * WH + j1 * W + i1);
+    const f4 c00 = lerp4(v000, v100, a), c10 = lerp4(v010, v110, a);
+    const f4 c01 = lerp4(v001, v101, a), c11 = lerp4(v011, v111, a);
+    const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
+    return lerp4(c0, c1, c);
+}
+
+// bspline_weights (CubicInterpolationCUDA/code/internal/bspline_kernel.cu:83-94)
+__device__ __forceinline__ void bspline_weights(float f, float &w0, float &w1, float &w2, float &w3) {
+    const float one_frac = 1.0f - f;
+    const float squared = f * f;
+    const float one_sqd = one_frac * one_frac;
+    w0 = 1.0f / 6.0f * one_sqd * one_frac;
+    w1 = 2.0f / 3.0f - 0.5f * squared * (2.0f - f);
+    w2 = 2.0f / 3.0f - 0.5f * one_sqd * (2.0f - one_frac);
+    w3 = 1.0f / 6.0f * squared * f;
+}
+
+// Tricubic B-spline fetch on the prefiltered coefficients: separable 64-tap sum over texels
+// floor(x-0.5)-1 .. +2 (clamped), x innermost, each level an fmaf chain starting with a plain
+// product.  This is the exact form of what the reference evaluates with 8 hardware trilinear
+// fetches (cubicTex3D_kernel.cu:48-81; 64-tap equivalent: cubicTex3D.cu:63-90).
+__device__ __forceinline__ f4 tex3d_cubic(const VolumeDev &v, float x, float y, float z) {
+    const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
+    const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
+    float wx[4], wy[4], wz[4];
+    bspline_weights(xg - fi, wx[0], wx[1], wx[2], wx[3]);
+    bspline_weights(yg - fj, wy[0], wy[1], wy[2], wy[3]);
+    bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
+    int ix[4], iy[4], iz[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        ix[a] = clampi((int)fi - 1 + a, 0, v.nx - 1);
+        iy[a] = clampi((int)fj - 1 + a, 0, v.ny - 1);
+        iz[a] = clampi((int)fk - 1 + a, 0, v.nz - 1);
+    }
+    const size_t W = v.nx, WH = (size_t)v.nx * v.ny;
+    f4 acc = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        f4 plane = f4{0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const f4 *row = v.coeffs + iz[c] * WH + iy[b] * W;
+            const f4 t0 = ldtexel(row + ix[0]), t1 = ldtexel(row + ix[1]);
+            const f4 t2 = ldtexel(row + ix[2]), t3 = ldtexel(row + ix[3]);
+            f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
+            r = f4{fmaf(wx[1], t1.x, r.x), fmaf(wx[1], t1.y, r.y), fmaf(wx[1], t1.z, r.z), fmaf(wx[1], t1.w, r.w)};
+            r = f4{fmaf(wx[2], t2.x, r.x), fmaf(wx[2], t2.y, r.y), fmaf(wx[2], t2.z, r.z), fmaf(wx[2], t2.w, r.w)};
+            r = f4{fmaf(wx[3], t3.x, r.x), fmaf(wx[3], t3.y, r.y), fmaf(wx[3], t3.z, r.z), fmaf(wx[3], t3.w, r.w)};
+            if (b == 0) plane = f4{wy[0] * r.x, wy[0] * r.y, wy[0] * r.z, wy[0] * r.w};
+            else plane = f4{fmaf(wy[b], r.x, plane.x), fmaf(wy[b], r.y, plane.y), fmaf(wy[b], r.z, plane.z),
+                            fmaf(wy[b], r.w, plane.w)};
+        }
+        if (c == 0) acc = f4{wz[0] * plane.x, wz[0] * plane.y, wz[0] * plane.z, wz[0] * plane.w};
+        else acc = f4{fmaf(wz[c], plane.x, acc.x), fmaf(wz[c], plane.y, acc.y), fmaf(wz[c], plane.z, acc.z),
+                      fmaf(wz[c], plane.w, acc.w)};
+    }
+    return acc;
+}
+
+// Slab test, restated with the reference's asymmetric z handling (.h:158-179).
+__device__ __forceinline__ bool intersect_with_volume(f3 &pos, f3 dir, f3 p1, f3 p2) {
+    float tnear = -(FLT_MAX - 1);
+    float tfar = FLT_MAX;
+    float t1 = (p1.x - pos.x) / dir.x, t2 = (p2.x - pos.x) / dir.x;
+    if (t1 > t2) { const float t = t1; t1 = t2; t2 = t; }
+    if (t1 > tnear) tnear = t1;
+    if (t2 < tfar) tfar = t2;
+    if (tnear > tfar) return false;
+    if (tfar < 0.0) return false;
+    t1 = (p1.y - pos.y) / dir.y; t2 = (p2.y - pos.y) / dir.y;
+    if (t1 > t2) { const float t = t1; t1 = t2; t2 = t; }
+    if (t1 > tnear) tnear = t1;
+    if (t2 < tfar) tfar = t2;
+    if (tnear > tfar) return false;
+    if (tfar < 0.0) return false;
+    t1 = (p1.z - pos.z) / dir.z; t2 = (p2.z - pos.z) / dir.z;
+    if (t1 > t2) { const float t = t1; t1 = t2; t2 = t; }
+    float t;
+    if (t1 >= 0 && t1 > tnear) tnear = t1;
+    if (t2 < tfar) tfar = t2;
+    if (tnear > tfar) return false;
+    if (tfar < 0.0) return false;
+    else if (tnear < 0) t = tfar;
+    else t = tnear;
+    pos.x += dir.x * t; pos.y += dir.y * t; pos.z += dir.z * t;
+    return true;
+}
+
+__device__ __forceinline__ f3 lookup_index(f3 pos, const VolumeDev &v, f3 scale) {     // .h:195-215
+    const f3 off = pos - v.min_bound;
+    const f3 fn = mk3(scale.x * off.x, scale.y * off.y, scale.z * off.z);
+    return mk3(1 + fn.x * (v.nx - 2), 1 + fn.y * (v.ny - 2), 1 + fn.z * (v.nz - 2));
+}
+__device__ __forceinline__ bool inside_box(f3 p, const VolumeDev &v, f3 l) {            // .h:217-251
+    if (p.x < v.min_bound.x || p.y < v.min_bound.y || p.z < v.min_bound.z ||
+        p.x >= v.max_bound.x || p.y >= v.max_bound.y || p.z >= v.max_bound.z) return false;
+    if (l.x < 0 || l.y < 0 || l.z < 0 || l.x >= v.nx || l.y >= v.ny || l.z >= v.nz) return false;
+    return true;
+}
+__device__ __forceinline__ bool can_access(const VolumeDev &v, f3 l) {                  // .h:253-277
+    return !(l.x < 0 || l.y < 0 || l.z < 0 || l.x >= v.nx || l.y >= v.ny || l.z >= v.nz);
+}
+
+constexpr int kLoopMax = 10000000;      // loop_ctr_max (.h:765,981)
+constexpr int kSpinMax = 1 << 20;       // bound on the reference's uncounted `continue` spins
+
+// linear-branch fetch with the reference's "n-1 below data_min" repair (.h:1052-1065)
+__device__ __forceinline__ f4 fetch_linear(const VolumeDev &v, f3 l, const f4 &prev, float ambient,
+                                           MarchCount &mc) {
+    f4 val = tex3d_linear(v, l.x, l.y, l.z);
+    mc.samples++;
+    if (val.w < v.data_min) {
+        if (prev.w == 0) {
+            const f4 t = tex3d_linear(v, l.x, l.y, l.z - 1);
+            mc.samples++;
+            val = f4{t.x, t.y, t.z, ambient - 1};
+        } else {
+            val = prev;
+        }
+    }
+    return val;
+}
+
+// Sharma-Kumar-Ghatak RK4 of the ray equation (.h:952-1291).  INTERP is a compile-time branch.
+template <int INTERP>
+__device__ __forceinline__ void rk4(f3 &rpos, f3 &rdir, const VolumeDev &v, f3 scale, MarchCount &mc) {
+    const float ambient = 1.000277;
+    int loop_ctr = 0, spins = 0;
+    f3 pos, lookup, R_n, T_n, A, B, C, D;
+    f4 val, val_prev = f4{0, 0, 0, 0};
+    float delta_t, current_n;
+    while (true) {
+        if (loop_ctr > kLoopMax) break;
+        pos = rpos;
+        lookup = lookup_index(pos, v, scale);
+        if (!inside_box(pos, v, lookup) && loop_ctr != 0) break;
+        if (!can_access(v, lookup)) {
+            pos = pos + v.step_size / (1 + v.data_min) * rdir;
+            rpos = pos;
+            if (++spins > kSpinMax) break;
+            continue;
+        }
+        if (INTERP == 1) {
+            val = fetch_linear(v, lookup, val_prev, ambient, mc);
+        } else {
+            val = tex3d_cubic(v, lookup.x, lookup.y, lookup.z);
+            mc.samples++;
+            if (val.w < v.data_min) {
+                pos = pos + v.step_size / (1 + v.data_min) * rdir;
+                rpos = pos;
+                if (++spins > kSpinMax) break;
+                continue;
+            }
+        }
+        loop_ctr += 1;
+        val.w += 1;
+        current_n = val.w;
+        R_n = pos;
+        delta_t = v.step_size / val.w;
+        T_n = val.w * rdir;
+        D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+        A = delta_t * D;
+        // reference: delta_t/2.0 and 1/8.0*delta_t in double, narrowed to float (.h:1088) --
+        // exact powers of two, so the f32 products below are the same values
+        pos = R_n + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;
+        lookup = lookup_index(pos, v, scale);
+        if (!inside_box(pos, v, lookup)) break;
+        if (INTERP == 1) {
+            val_prev = val; val_prev.w -= 1;
+            val = fetch_linear(v, lookup, val_prev, ambient, mc);
+        } else {
+            val = tex3d_cubic(v, lookup.x, lookup.y, lookup.z);
+            mc.samples++;
+        }
+        val.w += 1;
+        D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+        B = delta_t * D;
+        pos = R_n + delta_t * T_n + (0.5f * delta_t) * B;                  // .h:1131
+        lookup = lookup_index(pos, v, scale);
+        if (!inside_box(pos, v, lookup)) break;
+        if (INTERP == 1) {
+            val_prev = val; val_prev.w -= 1;
+            val = fetch_linear(v, lookup, val_prev, ambient, mc);
+        } else {
+            val = tex3d_cubic(v, lookup.x, lookup.y, lookup.z);
+            mc.samples++;
+        }
+        val.w += 1;
+        D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+        C = delta_t * D;
+        R_n = R_n + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));
+        T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);
+        if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
+        rpos = R_n;
+        // linear branch divides by the first sample's n (.h:1178), cubic by the last (.h:1276)
+        rdir = normalize(T_n / (INTERP == 1 ? current_n : val.w));
+        mc.iterations++;
+    }
+}
+
+// Euler integrator (.h:743-950), noise hook not built.
+template <int INTERP>
+__device__ __forceinline__ void euler(f3 &rpos, f3 &rdir, const VolumeDev &v, f3 scale, MarchCount &mc) {
+    const float ambient = 1.000277;
+    int loop_ctr = 0, spins = 0;
+    f3 pos, dir, lookup, normal;
+    f4 val, val_prev = f4{0, 0, 0, 0};
+    while (true) {
+        if (loop_ctr > kLoopMax) break;
+        pos = rpos; dir = rdir;
+        lookup = lookup_index(pos, v, scale);
+        if (!inside_box(pos, v, lookup) && loop_ctr != 0) break;
+        if (INTERP == 1) {
+            if (!can_access(v, lookup)) {
+                pos = pos + v.step_size / (1 + v.data_min) * dir;
+                rpos = pos;
+                if (++spins > kSpinMax) break;
+                continue;
+            }
+            val = fetch_linear(v, lookup, val_prev, ambient, mc);
+            const float current_n = 1 + val.w;
+            normal = mk3(val.x, val.y, val.z);
+            dir = dir + v.step_size * normal;
+            pos = pos + v.step_size / current_n * dir;
+            rpos = pos; rdir = dir;
+            val_prev = val;
+            loop_ctr += 1;
+        } else {
+            val = tex3d_cubic(v, lookup.x, lookup.y, lookup.z);
+            mc.samples++;
+            if (val.w < v.data_min) {
+                pos = pos + v.step_size / (1 + v.data_min) * dir;
+                rpos = pos;
+                if (++spins > kSpinMax) break;
+                continue;
+            }
+            loop_ctr += 1;
+            normal = mk3(val.x, val.y, val.z);
+            dir = dir + v.step_size * normal;
+            dir = normalize(dir);
+            const float n = 1 + val.w;
+            pos = pos + dir * v.step_size / n;
+            rpos = pos; rdir = dir;
+        }
+        mc.iterations++;
+    }
+}
+
+// trace_rays_through_density_gradients (.h:1455-1544): entry test + integrator dispatch.
+template <int ALGO, int INTERP>
+__device__ __forceinline__ void trace_volume(f3 &pos_io, f3 &dir_io, const VolumeDev &v, MarchCount &mc) {
+    const f3 mn = v.min_bound, mx = v.max_bound;
+    const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
+    f3 pos = pos_io;
+    const f3 dir = dir_io;
+    if (pos.x <= mn.x || pos.y <= mn.y || pos.z <= mn.z || pos.x >= mx.x || pos.y >= mx.y || pos.z >= mx.z) {
+        if (!intersect_with_volume(pos, dir, mn, mx)) return;       // miss: ray left unchanged
+    }
+    pos_io = pos;
+    if (ALGO == 1) euler<INTERP>(pos_io, dir_io, v, scale, mc);
+    else rk4<INTERP>(pos_io, dir_io, v, scale, mc);
+}
+
+}  // namespace photon

@@ -1,0 +1,910 @@
+// photon_core.hip - libparallel_ray_tracing.so for AMD Instinct MI355X (gfx950).
+//
+// Hand-written HIP implementation of photon's ray-tracing core behind the reference's C-ABI
+// (include/parallel_ray_tracing.h).  What runs where:
+//
+//   host   start_ray_tracing / photon_*      argument marshalling, NRRD parse, chunk loop, dumps
+//   GPU    build_volume_kernel               density -> (grad n, n-1) float4 texels
+//          prefilter_lines_kernel x3         cubic B-spline prefilter, per channel (x, y, z lines)
+//          march_kernel<ALGO,INTERP>         ray generation + Mie lookup + world transform +
+//                                            Euler/RK4 march through the volume -> SoA ray state
+//          sensor_kernel<FROM_STATE>         (ray generation |) lens / aperture / apparent image
+//                                            + erf or 4-pixel splat with f32 atomics
+//
+// The product has no CPU compute path: if HIP reports an error the call fails loudly
+// (message on stderr, non-zero return / untouched image).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (photon_amd/build.py).
+
+#include <hip/hip_runtime.h>
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/parallel_ray_tracing.h"
+#include "device_optics.hpp"
+#include "device_vec.hpp"
+#include "device_volume.hpp"
+
+using namespace photon;
+
+// =============================================================================================
+// error handling
+// =============================================================================================
+#define PH_CHECK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            fprintf(stderr, "photon: HIP error %d (%s) at %s:%d: %s\n", (int)_e,                \
+                    hipGetErrorString(_e), __FILE__, __LINE__, #expr);                          \
+            return (int)_e;                                                                     \
+        }                                                                                       \
+    } while (0)
+
+static bool verbose() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PHOTON_VERBOSE"); v = (e && atoi(e) > 0) ? 1 : 0; }
+    return v == 1;
+}
+
+// =============================================================================================
+// device-side aggregates
+// =============================================================================================
+struct RayStateDev {                // SoA ray state between the march and the sensor stage
+    float *px, *py, *pz, *dx, *dy, *dz;
+    double *radiance;
+};
+
+struct DumpDev {                    // ray dumps (save_lightrays), indexed by chunk-global ray id
+    float *final_pos;               // [num_save][3] or nullptr
+    float *final_dir;
+    int num_save;
+};
+
+enum { CNT_ON_SENSOR = 0, CNT_ITER = 1, CNT_SAMPLES = 2, CNT_TAPS = 3, CNT_N = 4 };
+
+// Blocks b and b+8 share an XCD (round-robin dispatch); rays are ordered source-major, so giving
+// each XCD a contiguous range of logical blocks keeps rays that walk the same voxels on one L2.
+// Bijective for any grid size.  Speed only -- never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
+    const unsigned q = nb >> 3, rem = nb & 7u, xcd = bid & 7u, idx = bid >> 3;
+    const unsigned start = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    return start + idx;
+}
+
+__device__ __forceinline__ void wave_add(unsigned long long *dst, unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+// =============================================================================================
+// volume construction kernels
+// =============================================================================================
+
+// setData (trace_rays_through_density_gradients.h:1820-2002) with loadNRRD's Gladstone-Dale
+// scaling (.h:1729-1748) folded in: one thread per voxel; edges use the double-precision
+// one-sided stencils, the interior the f32 (x, z) / f64-divisor (y) central differences.
+__global__ __launch_bounds__(256) void build_volume_kernel(const float *__restrict__ rho, int W, int H, int D,
+                                                           float gx, float gy, float gz, f4 *__restrict__ out,
+                                                           float *__restrict__ block_min) {
+    const size_t n = (size_t)W * H * D;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float K = 0.225e-3;
+    float mine = FLT_MAX;
+    if (i < n) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((size_t)W * H));
+        const size_t WH = (size_t)W * H;
+        auto d = [&](int xx, int yy, int zz) { return K * (rho[zz * WH + (size_t)yy * W + xx] * 1.0f); };
+        float nxv, nyv, nzv, s1, s2, s3;
+        if (x < 1) {
+            s1 = d(x, y, z); s2 = d(x + 1, y, z); s3 = d(x + 2, y, z);
+            nxv = (float)((-3.0 / 2 * s1 + 2 * s2 - 1.0 / 2 * s3) / gx);
+        } else if (x >= W - 1) {
+            s1 = d(x, y, z); s2 = d(x - 1, y, z); s3 = d(x - 2, y, z);
+            nxv = (float)((3.0 / 2 * s1 - 2 * s2 + 1.0 / 2 * s3) / gx);
+        } else {
+            s1 = d(x - 1, y, z); s2 = d(x + 1, y, z);
+            nxv = (s2 - s1) / (2 * gx);
+        }
+        if (y < 1) {
+            s1 = d(x, y, z); s2 = d(x, y + 1, z); s3 = d(x, y + 2, z);
+            nyv = (float)((-3.0 / 2 * s1 + 2 * s2 - 1.0 / 2 * s3) / gy);
+        } else if (y >= H - 1) {
+            s1 = d(x, y, z); s2 = d(x, y - 1, z); s3 = d(x, y - 2, z);
+            nyv = (float)((3.0 / 2 * s1 - 2 * s2 + 1.0 / 2 * s3) / gy);
+        } else {
+            s1 = d(x, y - 1, z); s2 = d(x, y + 1, z);
+            nyv = (float)((s2 - s1) / (2.0 * gy));
+        }
+        if (z < 1) {
+            s1 = d(x, y, z); s2 = d(x, y, z + 1); s3 = d(x, y, z + 2);
+            nzv = (float)((-3.0 / 2 * s1 + 2 * s2 - 1.0 / 2 * s3) / gz);
+        } else if (z >= D - 1) {
+            s1 = d(x, y, z); s2 = d(x, y, z - 1); s3 = d(x, y, z - 2);
+            nzv = (float)((3.0 / 2 * s1 - 2 * s2 + 1.0 / 2 * s3) / gz);
+        } else {
+            s1 = d(x, y, z - 1); s2 = d(x, y, z + 1);
+            nzv = (s2 - s1) / (2 * gz);
+        }
+        const float w = d(x, y, z);
+        *reinterpret_cast<float4 *>(out + i) = make_float4(nxv, nyv, nzv, w);
+        mine = w;
+    }
+    // block minimum of n-1 (data_min, .h:1868-1869)
+    __shared__ float red[256];
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_min[blockIdx.x] = red[0];
+}
+
+// ConvertToInterpolationCoefficients (cubicPrefilter_kernel.cu:52-112) on all four channels of one
+// line of float4 texels, in place.  One thread per line; `lines_inner` lines are adjacent in
+// memory by `inner_stride` texels (coalesced for the y and z passes).
+__global__ __launch_bounds__(256) void prefilter_lines_kernel(f4 *vol, int len, size_t len_stride, int lines_inner,
+                                                              size_t inner_stride, int lines_outer,
+                                                              size_t outer_stride) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)lines_inner * lines_outer) return;
+    const size_t li = t % lines_inner, lo = t / lines_inner;
+    f4 *c = vol + lo * outer_stride + li * inner_stride;
+    const float Pole = sqrtf(3.0f) - 2.0f;
+    const float Lambda = (1.0f - Pole) * (1.0f - 1.0f / Pole);
+    const int horizon = len < 12 ? len : 12;
+    float zn = Pole;
+    f4 first = c[0];
+    f4 sum = first;
+    for (int k = 0; k < horizon; k++) {
+        const f4 v = c[k * len_stride];
+        sum.x += zn * v.x; sum.y += zn * v.y; sum.z += zn * v.z; sum.w += zn * v.w;
+        zn *= Pole;
+    }
+    f4 prev = f4{Lambda * sum.x, Lambda * sum.y, Lambda * sum.z, Lambda * sum.w};
+    c[0] = prev;
+    for (int k = 1; k < len; k++) {
+        const f4 v = c[k * len_stride];
+        prev = f4{Lambda * v.x + Pole * prev.x, Lambda * v.y + Pole * prev.y, Lambda * v.z + Pole * prev.z,
+                  Lambda * v.w + Pole * prev.w};
+        c[k * len_stride] = prev;
+    }
+    const float g = Pole / (Pole - 1.0f);
+    const f4 last = c[(size_t)(len - 1) * len_stride];
+    prev = f4{g * last.x, g * last.y, g * last.z, g * last.w};
+    c[(size_t)(len - 1) * len_stride] = prev;
+    for (int k = len - 2; k >= 0; k--) {
+        const f4 v = c[k * len_stride];
+        prev = f4{Pole * (prev.x - v.x), Pole * (prev.y - v.y), Pole * (prev.z - v.z), Pole * (prev.w - v.w)};
+        c[k * len_stride] = prev;
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(VolumeDev v, int n, const float *__restrict__ coords,
+                                                     float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    const f4 r = v.interpolation == 2 ? tex3d_cubic(v, x, y, z) : tex3d_linear(v, x, y, z);
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+template <int ALGO, int INTERP>
+__global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, int n, float *pos, float *dir, int *steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 p = mk3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+    f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    MarchCount mc{0, 0};
+    trace_volume<ALGO, INTERP>(p, d, v, mc);
+    pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+    if (steps) steps[i] = mc.iterations;
+}
+
+// =============================================================================================
+// the two ray-tracing kernels
+// =============================================================================================
+
+// Stage 1 (density gradients on): generate the ray, move it to the volume's world frame, march
+// it, move it back (parallel_ray_tracing.cu:2004-2131), store the state SoA.  One lane per ray,
+// rays source-major so the 64 lanes of a wave start from (almost) the same point.
+template <int ALGO, int INTERP>
+__global__ __launch_bounds__(256) void march_kernel(SceneDev sc, VolumeDev vol, long long src_begin, unsigned n_rays,
+                                                    RayStateDev st, unsigned long long *counters) {
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned r = bid * blockDim.x + threadIdx.x;
+    MarchCount mc{0, 0};
+    if (r < n_rays) {
+        const unsigned rps = (unsigned)sc.rays_per_source;
+        const int source = (int)(src_begin + r / rps);
+        const int local_ray = (int)(r % rps);
+        Ray ray = generate_ray(sc, source, local_ray);
+        f3 p = ray.pos, d = ray.dir;
+        p.z = (float)(p.z - (sc.z_offset + 750e3));                     // .cu:2045
+        p = matvec(sc.cam.inverse_rotation_matrix, p);                  // camera -> world
+        d = matvec(sc.cam.inverse_rotation_matrix, d);
+        trace_volume<ALGO, INTERP>(p, d, vol, mc);
+        p = matvec(sc.cam.rotation_matrix, p);                          // world -> camera
+        d = normalize(matvec(sc.cam.rotation_matrix, d));
+        p.z = (float)(p.z + (sc.z_offset + 750e3));                     // .cu:2119
+        st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
+        st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+        st.radiance[r] = ray.radiance;
+    }
+    wave_add(&counters[CNT_ITER], (unsigned long long)mc.iterations);
+    wave_add(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
+}
+
+// Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241).  FROM_STATE=false
+// (no density gradients) generates the ray in place, so that path is one fused kernel.
+template <bool FROM_STATE>
+__global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
+                                                     float *image, DumpDev dump, unsigned long long *counters) {
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    int taps = 0;
+    unsigned on_sensor = 0;
+    if (r < n_rays) {
+        Ray ray;
+        bool alive = true;
+        if (FROM_STATE) {
+            ray.pos = mk3(st.px[r], st.py[r], st.pz[r]);
+            ray.dir = mk3(st.dx[r], st.dy[r], st.dz[r]);
+            ray.radiance = st.radiance[r];
+            ray.wavelength = sc.beam_wavelength;
+            alive = !(isnan3(ray.dir) || isnan3(ray.pos));              // .cu:2125-2129
+        } else {
+            const unsigned rps = (unsigned)sc.rays_per_source;
+            ray = generate_ray(sc, (int)(src_begin + r / rps), (int)(r % rps));
+        }
+        const bool dumping = dump.final_pos != nullptr && r < (unsigned)dump.num_save;
+        f3 fin = nan3();
+        bool have_fin = false;
+        if (alive) {
+            if (dumping) {                                              // .cu:2136-2141
+                dump.final_dir[3 * r] = ray.dir.x; dump.final_dir[3 * r + 1] = ray.dir.y;
+                dump.final_dir[3 * r + 2] = ray.dir.z;
+            }
+            if (sc.elems[0].element_type == 'n') {                      // .cu:2143-2158
+                const float z_obj = sc.object_distance + sc.z_offset;
+                fin = apparent_image(image, ray, sc.cam, z_obj, sc.z_offset, sc.elems[0], taps);
+                have_fin = true;
+                on_sensor = !isnan(fin.x);
+            } else {
+                ray = optical_system(sc, ray);
+                if (!(isnan3(ray.dir) || isnan3(ray.pos))) {            // .cu:2172-2176
+                    if (sc.cam.implement_diffraction) {
+                        fin = sensor_diffraction(image, ray, sc.cam, taps);
+                        have_fin = true;
+                        on_sensor = !isnan(fin.x);
+                    } else {
+                        fin = sensor_bilinear(image, ray, sc.cam, taps);
+                        have_fin = !(isnan(fin.x) || isnan(fin.y));     // .cu:2196
+                        on_sensor = have_fin;
+                    }
+                }
+            }
+        }
+        if (dumping && have_fin) {
+            dump.final_pos[3 * r] = fin.x; dump.final_pos[3 * r + 1] = fin.y; dump.final_pos[3 * r + 2] = fin.z;
+        }
+    }
+    wave_add(&counters[CNT_TAPS], (unsigned long long)taps);
+    wave_add(&counters[CNT_ON_SENSOR], (unsigned long long)on_sensor);
+}
+
+// =============================================================================================
+// host: handles
+// =============================================================================================
+struct photon_volume {
+    VolumeDev dev{};
+    photon_volume_info_t info{};
+    f4 *d_texels = nullptr;
+    f4 *d_coeffs = nullptr;
+};
+
+struct photon_scene {
+    SceneDev dev{};
+    std::vector<void *> allocs;         // device buffers owned by the scene
+    RayStateDev ws{};                   // march -> sensor state, grown on demand
+    size_t ws_rays = 0;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+template <typename T>
+static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
+    T *d = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    PH_CHECK(hipMalloc((void **)&d, bytes));
+    s->allocs.push_back(d);
+    if (n) PH_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = d;
+    return 0;
+}
+
+// glibc rand()/srand() sequence (TYPE_3 additive-feedback generator r[i] = r[i-3] + r[i-31]),
+// re-implemented so the lens-sample table of parallel_ray_tracing.cu:3228-3235 is reproduced
+// without touching the caller's process-wide rand() state.
+static void glibc_rand_sequence(unsigned seed, int count, std::vector<int> &out) {
+    std::vector<int32_t> r(344 + count);
+    r[0] = (int32_t)seed;
+    for (int i = 1; i < 31; i++) {
+        const int64_t hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        int64_t word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        r[i] = (int32_t)word;
+    }
+    for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+    for (int i = 34; i < 344 + count; i++) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+    out.resize(count);
+    for (int i = 0; i < count; i++) out[i] = (int)((uint32_t)r[344 + i] >> 1);
+}
+
+static bool parse_nrrd(const char *path, std::vector<float> &rho, int dims[3], double spacing[3], double origin[3],
+                       std::string &why) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { why = "cannot open file"; return false; }
+    std::string line;
+    if (!std::getline(f, line) || line.rfind("NRRD", 0) != 0) { why = "missing NRRD magic"; return false; }
+    std::string type, encoding = "raw", endian = "little";
+    int dimension = 0;
+    bool sizes_ok = false;
+    for (int a = 0; a < 3; a++) { spacing[a] = 1.0; origin[a] = 0.0; }
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) break;                        // blank line ends the header
+        if (line[0] == '#') continue;
+        const size_t colon = line.find(':');
+        if (colon == std::string::npos) continue;
+        const std::string key = line.substr(0, colon);
+        size_t vs = colon + 1;
+        if (vs < line.size() && line[vs] == '=') vs++;  // "key:=value" pairs
+        while (vs < line.size() && line[vs] == ' ') vs++;
+        const std::string val = line.substr(vs);
+        if (key == "type") type = val;
+        else if (key == "dimension") dimension = atoi(val.c_str());
+        else if (key == "encoding") encoding = val;
+        else if (key == "endian") endian = val;
+        else if (key == "sizes") sizes_ok = sscanf(val.c_str(), "%d %d %d", &dims[0], &dims[1], &dims[2]) == 3;
+        else if (key == "spacings") sscanf(val.c_str(), "%lf %lf %lf", &spacing[0], &spacing[1], &spacing[2]);
+        else if (key == "space origin") sscanf(val.c_str(), " (%lf,%lf,%lf)", &origin[0], &origin[1], &origin[2]);
+        else if (key == "space directions") {
+            double m[9];
+            if (sscanf(val.c_str(), " (%lf,%lf,%lf) (%lf,%lf,%lf) (%lf,%lf,%lf)", &m[0], &m[1], &m[2], &m[3], &m[4],
+                       &m[5], &m[6], &m[7], &m[8]) == 9)
+                for (int a = 0; a < 3; a++)
+                    spacing[a] = std::sqrt(m[3 * a] * m[3 * a] + m[3 * a + 1] * m[3 * a + 1] + m[3 * a + 2] * m[3 * a + 2]);
+        }
+    }
+    if (dimension != 3 || !sizes_ok) { why = "need dimension 3 with three sizes"; return false; }
+    if (type != "float") { why = "type must be float (single precision)"; return false; }
+    if (encoding != "raw" || endian != "little") { why = "only raw little-endian encoding is supported"; return false; }
+    if (dims[0] < 3 || dims[1] < 3 || dims[2] < 3) { why = "each axis needs at least 3 samples"; return false; }
+    rho.resize((size_t)dims[0] * dims[1] * dims[2]);
+    f.read(reinterpret_cast<char *>(rho.data()), (std::streamsize)(rho.size() * sizeof(float)));
+    if ((size_t)f.gcount() != rho.size() * sizeof(float)) { why = "payload shorter than sizes"; return false; }
+    return true;
+}
+
+// =============================================================================================
+// C-ABI: extension entry points
+// =============================================================================================
+extern "C" {
+
+const char *photon_version(void) { return "photon-amd 0.1 (gfx950, HIP)"; }
+
+int photon_set_device(int device) {
+    PH_CHECK(hipSetDevice(device));
+    return 0;
+}
+
+int photon_rand_table(int n, float *r1, float *r2) {
+    if (n < 0) return 1;
+    std::vector<int> seq;
+    glibc_rand_sequence(10u, 2 * n, seq);
+    for (int k = 0; k < n; k++) {                       // RAND_MAX = 2147483647
+        r1[k] = (float)((double)seq[2 * k] / 2147483647);
+        r2[k] = (float)((double)seq[2 * k + 1] / 2147483647);
+    }
+    return 0;
+}
+
+void photon_volume_free(photon_volume_t *vol) {
+    if (!vol) return;
+    if (vol->d_texels) (void)hipFree(vol->d_texels);
+    if (vol->d_coeffs) (void)hipFree(vol->d_coeffs);
+    delete vol;
+}
+
+int photon_volume_from_density(const float *rho, int nx, int ny, int nz, const double spacing[3],
+                               const double origin[3], int interpolation, photon_volume_t **out) {
+    if (!rho || !out || nx < 3 || ny < 3 || nz < 3 || (interpolation != 1 && interpolation != 2)) {
+        fprintf(stderr, "photon: photon_volume_from_density: bad arguments\n");
+        return 1;
+    }
+    // bounds from the file's own size (loadNRRD, .h:1696-1706), then the 1024-slice cap (.h:1714-1717)
+    const double xmin = origin[0], ymin = origin[1], zmin = origin[2] - 750e3;
+    const double xmax = xmin + (nx - 1) * spacing[0], ymax = ymin + (ny - 1) * spacing[1];
+    const double zmax = zmin + (nz - 1) * spacing[2];
+    if (nz > 1024) nz = 1024;
+    photon_volume *v = new photon_volume();
+    const size_t n = (size_t)nx * ny * nz;
+    float *d_rho = nullptr, *d_min = nullptr;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    auto fail = [&](int code) { if (d_rho) (void)hipFree(d_rho); if (d_min) (void)hipFree(d_min); photon_volume_free(v); return code; };
+#define PH_VCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fprintf(stderr, "photon: HIP error %d (%s) at %s:%d\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); return fail((int)_e); } } while (0)
+    PH_VCHECK(hipMalloc((void **)&v->d_texels, n * sizeof(f4)));
+    PH_VCHECK(hipMalloc((void **)&d_rho, n * sizeof(float)));
+    PH_VCHECK(hipMalloc((void **)&d_min, blocks * sizeof(float)));
+    PH_VCHECK(hipMemcpy(d_rho, rho, n * sizeof(float), hipMemcpyHostToDevice));
+    const float gx = (float)spacing[0], gy = (float)spacing[1], gz = (float)spacing[2];
+    hipLaunchKernelGGL(build_volume_kernel, dim3(blocks), dim3(256), 0, 0, d_rho, nx, ny, nz, gx, gy, gz, v->d_texels,
+                       d_min);
+    PH_VCHECK(hipGetLastError());
+    std::vector<float> mins(blocks);
+    PH_VCHECK(hipMemcpy(mins.data(), d_min, blocks * sizeof(float), hipMemcpyDeviceToHost));
+    float data_min = FLT_MAX;
+    for (float m : mins) if (m < data_min) data_min = m;
+    if (interpolation == 2) {
+        PH_VCHECK(hipMalloc((void **)&v->d_coeffs, n * sizeof(f4)));
+        PH_VCHECK(hipMemcpy(v->d_coeffs, v->d_texels, n * sizeof(f4), hipMemcpyDeviceToDevice));
+        const size_t sx = 1, sy = (size_t)nx, sz = (size_t)nx * ny;
+        auto nblk = [](size_t lines) { return dim3((unsigned)((lines + 255) / 256)); };
+        // x lines: (y inner, z outer); y lines: (x inner, z outer); z lines: (x inner, y outer)
+        hipLaunchKernelGGL(prefilter_lines_kernel, nblk((size_t)ny * nz), dim3(256), 0, 0, v->d_coeffs, nx, sx, ny, sy, nz, sz);
+        hipLaunchKernelGGL(prefilter_lines_kernel, nblk((size_t)nx * nz), dim3(256), 0, 0, v->d_coeffs, ny, sy, nx, sx, nz, sz);
+        hipLaunchKernelGGL(prefilter_lines_kernel, nblk((size_t)nx * ny), dim3(256), 0, 0, v->d_coeffs, nz, sz, nx, sx, ny, sy);
+        PH_VCHECK(hipGetLastError());
+    }
+    PH_VCHECK(hipDeviceSynchronize());
+    (void)hipFree(d_rho); d_rho = nullptr;
+    (void)hipFree(d_min); d_min = nullptr;
+#undef PH_VCHECK
+    float step = (float)fmin(spacing[0], spacing[1]);                   // .h:2086-2098
+    step = step < spacing[2] ? step : (float)spacing[2];
+    VolumeDev &d = v->dev;
+    d.min_bound = f3{(float)xmin, (float)ymin, (float)zmin};
+    d.max_bound = f3{(float)xmax, (float)ymax, (float)zmax};
+    d.nx = nx; d.ny = ny; d.nz = nz;
+    d.step_size = step;
+    d.data_min = data_min;
+    d.interpolation = interpolation;
+    d.texels = v->d_texels;
+    d.coeffs = v->d_coeffs;
+    photon_volume_info_t &info = v->info;
+    info.min_bound[0] = d.min_bound.x; info.min_bound[1] = d.min_bound.y; info.min_bound[2] = d.min_bound.z;
+    info.max_bound[0] = d.max_bound.x; info.max_bound[1] = d.max_bound.y; info.max_bound[2] = d.max_bound.z;
+    info.nx = nx; info.ny = ny; info.nz = nz;
+    info.grid_spacing[0] = gx; info.grid_spacing[1] = gy; info.grid_spacing[2] = gz;
+    info.step_size = step; info.data_min = data_min; info.interpolation = interpolation;
+    *out = v;
+    return 0;
+}
+
+int photon_volume_load_nrrd(const char *path, int interpolation, photon_volume_t **out) {
+    std::vector<float> rho;
+    int dims[3];
+    double spacing[3], origin[3];
+    std::string why;
+    if (!parse_nrrd(path, rho, dims, spacing, origin, why)) {
+        fprintf(stderr, "photon: failed to read NRRD \"%s\": %s\n", path ? path : "(null)", why.c_str());
+        return 2;
+    }
+    if (verbose())
+        printf("photon: NRRD %s  sizes %d %d %d  spacings %g %g %g  origin (%g,%g,%g)\n", path, dims[0], dims[1], dims[2],
+               spacing[0], spacing[1], spacing[2], origin[0], origin[1], origin[2]);
+    return photon_volume_from_density(rho.data(), dims[0], dims[1], dims[2], spacing, origin, interpolation, out);
+}
+
+int photon_volume_info(const photon_volume_t *vol, photon_volume_info_t *info) {
+    if (!vol || !info) return 1;
+    *info = vol->info;
+    return 0;
+}
+
+int photon_volume_download(const photon_volume_t *vol, int coefficients, float *out) {
+    if (!vol || !out) return 1;
+    const f4 *src = (coefficients && vol->d_coeffs) ? vol->d_coeffs : vol->d_texels;
+    const size_t n = (size_t)vol->dev.nx * vol->dev.ny * vol->dev.nz;
+    PH_CHECK(hipMemcpy(out, src, n * sizeof(f4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int photon_volume_sample(const photon_volume_t *vol, int n, const float *coords, float *out) {
+    if (!vol || n < 0) return 1;
+    if (n == 0) return 0;
+    float *d_c = nullptr, *d_o = nullptr;
+    PH_CHECK(hipMalloc((void **)&d_c, (size_t)n * 3 * sizeof(float)));
+    PH_CHECK(hipMalloc((void **)&d_o, (size_t)n * 4 * sizeof(float)));
+    PH_CHECK(hipMemcpy(d_c, coords, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sample_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, vol->dev, n, d_c, d_o);
+    PH_CHECK(hipGetLastError());
+    PH_CHECK(hipMemcpy(out, d_o, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_c); (void)hipFree(d_o);
+    return 0;
+}
+
+int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorithm, int n, float *pos, float *dir,
+                             int *steps) {
+    if (!vol || n < 0 || (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2)) {
+        fprintf(stderr, "photon: photon_trace_volume_rays: unsupported algorithm %d (1 euler, 2 rk4)\n",
+                ray_tracing_algorithm);
+        return 1;
+    }
+    if (n == 0) return 0;
+    float *d_p = nullptr, *d_d = nullptr;
+    int *d_s = nullptr;
+    const size_t b3 = (size_t)n * 3 * sizeof(float);
+    PH_CHECK(hipMalloc((void **)&d_p, b3));
+    PH_CHECK(hipMalloc((void **)&d_d, b3));
+    PH_CHECK(hipMalloc((void **)&d_s, (size_t)n * sizeof(int)));
+    PH_CHECK(hipMemcpy(d_p, pos, b3, hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(d_d, dir, b3, hipMemcpyHostToDevice));
+    const dim3 grid((n + 255) / 256), block(256);
+    const int interp = vol->dev.interpolation;
+    if (ray_tracing_algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_rays_kernel<1, 1>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    else if (ray_tracing_algorithm == 1) hipLaunchKernelGGL((march_rays_kernel<1, 2>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    else if (interp == 1) hipLaunchKernelGGL((march_rays_kernel<2, 1>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    else hipLaunchKernelGGL((march_rays_kernel<2, 2>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    PH_CHECK(hipGetLastError());
+    PH_CHECK(hipMemcpy(pos, d_p, b3, hipMemcpyDeviceToHost));
+    PH_CHECK(hipMemcpy(dir, d_d, b3, hipMemcpyDeviceToHost));
+    if (steps) PH_CHECK(hipMemcpy(steps, d_s, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(d_p); (void)hipFree(d_d); (void)hipFree(d_s);
+    return 0;
+}
+
+void photon_scene_free(photon_scene_t *s) {
+    if (!s) return;
+    for (void *p : s->allocs) (void)hipFree(p);
+    if (s->ws.px) (void)hipFree(s->ws.px);
+    if (s->ws.radiance) (void)hipFree(s->ws.radiance);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int photon_scene_create(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                        const char *scattering_type_str, const lightfield_source_t *lsp,
+                        int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
+                        int num_elements, const double (*element_center)[3], const element_data_t *edp,
+                        const double (*element_plane_parameters)[4], const int *element_system_index,
+                        const camera_design_t *cam, float ray_cone_pitch_ratio, photon_scene_t **out) {
+    if (!sdp || !scattering_type_str || !lsp || !edp || !cam || !out || !element_center || !element_plane_parameters ||
+        !element_system_index) {
+        fprintf(stderr, "photon: photon_scene_create: null argument\n");
+        return 1;
+    }
+    if (num_elements < 1 || num_elements > kMaxElements) {
+        fprintf(stderr, "photon: %d optical elements given, 1..%d supported\n", num_elements, kMaxElements);
+        return 1;
+    }
+    if (lightray_number_per_particle < 1 || lsp->num_particles < 0) {
+        fprintf(stderr, "photon: bad ray / source counts\n");
+        return 1;
+    }
+    photon_scene *s = new photon_scene();
+    SceneDev &d = s->dev;
+    int rc = 0;
+    auto bail = [&](int code) { photon_scene_free(s); return code; };
+    d.lens_pitch = lens_pitch; d.image_distance = image_distance; d.beam_wavelength = beam_wavelength;
+    d.f_number = aperture_f_number; d.ratio = ray_cone_pitch_ratio;
+    d.scattering_type = strcmp(scattering_type_str, "mie") == 0 ? 1 : 0;       // .cu:3192
+    d.rays_per_source = lightray_number_per_particle;
+    const size_t ns = (size_t)lsp->num_particles;
+    d.num_sources = (int)ns;
+    if ((rc = upload(s, lsp->x, ns, &d.sx))) return bail(rc);
+    if ((rc = upload(s, lsp->y, ns, &d.sy))) return bail(rc);
+    if ((rc = upload(s, lsp->z, ns, &d.sz))) return bail(rc);
+    if ((rc = upload(s, lsp->radiance, ns, &d.sradiance))) return bail(rc);
+    if ((rc = upload(s, lsp->diameter_index, ns, &d.sdia))) return bail(rc);
+    d.z_offset = lsp->z_offset; d.object_distance = lsp->object_distance;
+    memcpy(d.mie_inv_rot, sdp->inverse_rotation_matrix, sizeof d.mie_inv_rot);
+    memcpy(d.beam, sdp->beam_propagation_vector, sizeof d.beam);
+    d.num_angles = sdp->num_angles; d.num_diameters = sdp->num_diameters;
+    if (d.scattering_type) {
+        if (sdp->num_angles < 2 || sdp->num_diameters < 1 || !sdp->scattering_angle || !sdp->scattering_irradiance) {
+            fprintf(stderr, "photon: \"mie\" scattering needs an angle/irradiance table\n");
+            return bail(1);
+        }
+        if ((rc = upload(s, sdp->scattering_angle, (size_t)sdp->num_angles, &d.mie_angle))) return bail(rc);
+        if ((rc = upload(s, sdp->scattering_irradiance, (size_t)sdp->num_angles * sdp->num_diameters, &d.mie_irr)))
+            return bail(rc);
+    }
+    std::vector<float> r1(lightray_number_per_particle), r2(lightray_number_per_particle);
+    photon_rand_table(lightray_number_per_particle, r1.data(), r2.data());
+    if ((rc = upload(s, r1.data(), r1.size(), &d.r1))) return bail(rc);
+    if ((rc = upload(s, r2.data(), r2.size(), &d.r2))) return bail(rc);
+    d.num_elements = num_elements;
+    for (int k = 0; k < num_elements; k++) {                                   // .cu:3256-3260
+        d.elems[k] = edp[k];
+        for (int j = 0; j < 3; j++) d.centers[k][j] = (float)element_center[k][j];
+        for (int j = 0; j < 4; j++) d.planes[k][j] = (float)element_plane_parameters[k][j];
+        d.sys_index[k] = element_system_index[k];
+    }
+    d.cam = *cam;
+    if (cam->x_pixel_number < 1 || cam->y_pixel_number < 1) {
+        fprintf(stderr, "photon: sensor needs at least one pixel\n");
+        return bail(1);
+    }
+    hipError_t e = hipMalloc((void **)&s->d_counters, CNT_N * sizeof(unsigned long long));
+    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    for (auto &ev : s->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) { fprintf(stderr, "photon: hipEventCreate failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    }
+    *out = s;
+    return 0;
+}
+
+}  // extern "C"
+
+// rays per launch: bounded so that 32-bit ray ids suffice and the state stays a few GB
+static const unsigned kMaxRaysPerLaunch = 1u << 26;
+
+static int ensure_workspace(photon_scene *s, size_t rays) {
+    if (s->ws_rays >= rays) return 0;
+    if (s->ws.px) { (void)hipFree(s->ws.px); s->ws.px = nullptr; }
+    if (s->ws.radiance) { (void)hipFree(s->ws.radiance); s->ws.radiance = nullptr; }
+    s->ws_rays = 0;
+    float *f = nullptr;
+    PH_CHECK(hipMalloc((void **)&f, rays * 6 * sizeof(float)));
+    s->ws.px = f; s->ws.py = f + rays; s->ws.pz = f + 2 * rays;
+    s->ws.dx = f + 3 * rays; s->ws.dy = f + 4 * rays; s->ws.dz = f + 5 * rays;
+    PH_CHECK(hipMalloc((void **)&s->ws.radiance, rays * sizeof(double)));
+    s->ws_rays = rays;
+    return 0;
+}
+
+// One launch group over sources [src_begin, src_end): n rays = sources * rays_per_source.
+static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
+                        long long src_end, float *d_image, DumpDev dump, hipStream_t stream, bool timed) {
+    const unsigned long long n64 = (unsigned long long)(src_end - src_begin) * (unsigned)s->dev.rays_per_source;
+    if (n64 == 0) return 0;
+    if (n64 > kMaxRaysPerLaunch) return 1;
+    const unsigned n = (unsigned)n64;
+    const dim3 block(256), grid((n + 255) / 256);
+    if (vol) {
+        int rc = ensure_workspace(s, n);
+        if (rc) return rc;
+        if (timed) PH_CHECK(hipEventRecord(s->ev[1], stream));
+        const int interp = vol->dev.interpolation;
+        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
+        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
+        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
+        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
+        PH_CHECK(hipGetLastError());
+        if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
+        hipLaunchKernelGGL((sensor_kernel<true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+    } else {
+        hipLaunchKernelGGL((sensor_kernel<false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+    }
+    PH_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_tracing_algorithm,
+                            int64_t src_begin, int64_t src_end, float *d_image, void *stream_p,
+                            photon_trace_stats_t *stats) {
+    if (!scene || !d_image || src_begin < 0 || src_end < src_begin || src_end > scene->dev.num_sources) {
+        fprintf(stderr, "photon: photon_trace: bad arguments (sources [%lld,%lld) of %d)\n", (long long)src_begin,
+                (long long)src_end, scene ? scene->dev.num_sources : -1);
+        return 1;
+    }
+    if (vol && ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) {
+        fprintf(stderr, "photon: ray_tracing_algorithm %d is not built (1 euler, 2 rk4)\n", ray_tracing_algorithm);
+        return 1;
+    }
+    hipStream_t stream = (hipStream_t)stream_p;
+    const unsigned rps = (unsigned)scene->dev.rays_per_source;
+    const long long max_sources = std::max<long long>(1, kMaxRaysPerLaunch / rps);
+    if (rps > kMaxRaysPerLaunch) { fprintf(stderr, "photon: too many rays per source\n"); return 1; }
+    if (stats) {
+        PH_CHECK(hipMemsetAsync(scene->d_counters, 0, CNT_N * sizeof(unsigned long long), stream));
+        PH_CHECK(hipEventRecord(scene->ev[0], stream));
+    }
+    float march_ms = 0.f;
+    const DumpDev no_dump{nullptr, nullptr, 0};
+    for (long long b = src_begin; b < src_end; b += max_sources) {
+        const long long e = std::min<long long>(src_end, b + max_sources);
+        const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, d_image, no_dump, stream, stats != nullptr);
+        if (rc) return rc;
+        if (stats && vol) {
+            PH_CHECK(hipEventSynchronize(scene->ev[2]));
+            float ms = 0.f;
+            PH_CHECK(hipEventElapsedTime(&ms, scene->ev[1], scene->ev[2]));
+            march_ms += ms;
+        }
+    }
+    if (stats) {
+        PH_CHECK(hipEventRecord(scene->ev[3], stream));
+        PH_CHECK(hipEventSynchronize(scene->ev[3]));
+        unsigned long long c[CNT_N];
+        PH_CHECK(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+        memset(stats, 0, sizeof *stats);
+        stats->rays_launched = (uint64_t)(src_end - src_begin) * rps;
+        stats->rays_on_sensor = c[CNT_ON_SENSOR];
+        stats->rk_iterations = c[CNT_ITER];
+        stats->volume_samples = c[CNT_SAMPLES];
+        stats->sensor_taps = c[CNT_TAPS];
+        stats->march_ms = march_ms;
+        PH_CHECK(hipEventElapsedTime(&stats->total_ms, scene->ev[0], scene->ev[3]));
+    }
+    return 0;
+}
+
+// =============================================================================================
+// C-ABI: the reference's entry point
+// =============================================================================================
+namespace {
+
+struct VolumeCache {                // the library stays loaded between photon's calls: keep the
+    std::string path;               // uploaded volume, keyed by (file, mtime, size, sampler)
+    long long mtime_ns = 0;
+    long long size = 0;
+    int interpolation = 0;
+    int device = -1;
+    photon_volume *vol = nullptr;
+};
+std::mutex g_cache_mutex;
+VolumeCache g_cache;
+
+int interpolation_from_env() {
+    const char *e = getenv("PHOTON_INTERP");
+    if (e && (strcmp(e, "cubic") == 0 || strcmp(e, "2") == 0)) return 2;
+    return 1;                       // the reference hard-codes interpolation_scheme = 1 (.cu:3330)
+}
+
+int cached_volume(const char *path, int interpolation, photon_volume **out) {
+    struct stat st;
+    if (stat(path, &st) != 0) {
+        fprintf(stderr, "photon: failed to open \"%s\"\n", path);
+        return 2;
+    }
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const long long mt = (long long)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    if (g_cache.vol && g_cache.path == path && g_cache.mtime_ns == mt && g_cache.size == (long long)st.st_size &&
+        g_cache.interpolation == interpolation && g_cache.device == device) {
+        *out = g_cache.vol;
+        return 0;
+    }
+    if (g_cache.vol) { photon_volume_free(g_cache.vol); g_cache.vol = nullptr; }
+    photon_volume *v = nullptr;
+    const int rc = photon_volume_load_nrrd(path, interpolation, &v);
+    if (rc) return rc;
+    g_cache.path = path; g_cache.mtime_ns = mt; g_cache.size = (long long)st.st_size;
+    g_cache.interpolation = interpolation; g_cache.device = device; g_cache.vol = v;
+    *out = v;
+    return 0;
+}
+
+bool write_dump(const char *dir, const char *prefix, int k, const std::vector<float> &v) {
+    char name[64];
+    snprintf(name, sizeof name, "%s%04d.bin", prefix, k);               // .cu:3574
+    const std::string full = std::string(dir) + "/" + name;
+    std::ofstream f(full.c_str(), std::ios::out | std::ios::binary);
+    if (!f) { fprintf(stderr, "photon: cannot write %s\n", full.c_str()); return false; }
+    f.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(v.size() * sizeof(float)));
+    return true;
+}
+
+}  // namespace
+
+extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scattering_data_t *scattering_data_p,
+                                  char *scattering_type_str, lightfield_source_t *lightfield_source_p,
+                                  int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
+                                  int num_elements, double (*element_center)[3], element_data_t *element_data_p,
+                                  double (*element_plane_parameters)[4], int *element_system_index,
+                                  camera_design_t *camera_design_p, float *image_array,
+                                  bool simulate_density_gradients, char *density_grad_filename, bool save_lightrays,
+                                  char *lightray_position_save_path, char *lightray_direction_save_path,
+                                  int num_lightrays_save, int ray_tracing_algorithm, bool add_pos_noise,
+                                  float pos_noise_std, bool add_ngrad_noise, float ngrad_noise_std,
+                                  float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
+                                  int num_intermediate_positions_save) {
+    (void)pos_noise_std; (void)ngrad_noise_std; (void)num_intermediate_positions_save;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!image_array || !camera_design_p || !lightfield_source_p) {
+        fprintf(stderr, "photon: start_ray_tracing: null argument; image left untouched\n");
+        return;
+    }
+    if (simulate_density_gradients && (add_pos_noise || add_ngrad_noise))
+        fprintf(stderr, "photon: warning: position / gradient noise hooks are not built in this version; ignored\n");
+    if (save_intermediate_ray_data)
+        fprintf(stderr, "photon: warning: intermediate ray dumps are not built in this version; ignored\n");
+    if (simulate_density_gradients && ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) {
+        fprintf(stderr, "photon: ray_tracing_algorithm %d (rk45 / adams-bashforth) is not built; image left untouched\n",
+                ray_tracing_algorithm);
+        return;
+    }
+    photon_scene *scene = nullptr;
+    float *d_image = nullptr, *d_fpos = nullptr, *d_fdir = nullptr;
+    auto cleanup = [&]() {
+        if (scene) photon_scene_free(scene);
+        if (d_image) (void)hipFree(d_image);
+        if (d_fpos) (void)hipFree(d_fpos);
+        if (d_fdir) (void)hipFree(d_fdir);
+    };
+#define PH_VOID(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fprintf(stderr, "photon: HIP error %d (%s) at %s:%d; image left untouched\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); cleanup(); return; } } while (0)
+    if (photon_scene_create(lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
+                            lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements,
+                            element_center, element_data_p, element_plane_parameters, element_system_index,
+                            camera_design_p, ray_cone_pitch_ratio, &scene)) {
+        fprintf(stderr, "photon: scene upload failed; image left untouched\n");
+        return;
+    }
+    photon_volume *vol = nullptr;
+    if (simulate_density_gradients) {
+        if (cached_volume(density_grad_filename, interpolation_from_env(), &vol)) { cleanup(); return; }
+    }
+    const int W = camera_design_p->x_pixel_number, H = camera_design_p->y_pixel_number;
+    const size_t npix = (size_t)W * H;
+    PH_VOID(hipMalloc((void **)&d_image, npix * sizeof(float)));
+    PH_VOID(hipMemcpy(d_image, image_array, npix * sizeof(float), hipMemcpyHostToDevice));     // .cu:3309
+
+    const long long num_particles = lightfield_source_p->num_particles;
+    const long long rps = lightray_number_per_particle;
+    int rc = 0;
+    if (save_lightrays && num_lightrays_save > 0) {
+        // the reference's chunking decides which rays land in which pos_/dir_ file (.cu:3366-3372,
+        // 3515-3611): chunks of source_point_number sources, one file pair per chunk
+        long long chunk = lightfield_source_p->source_point_number;
+        if (num_particles < chunk) chunk = num_particles;
+        if (chunk < 1) chunk = 1;
+        if ((unsigned long long)(chunk * rps) > kMaxRaysPerLaunch) {
+            fprintf(stderr, "photon: source_point_number*rays exceeds %u rays per launch; image left untouched\n", kMaxRaysPerLaunch);
+            cleanup();
+            return;
+        }
+        const size_t nsave = (size_t)num_lightrays_save * 3;
+        PH_VOID(hipMalloc((void **)&d_fpos, nsave * sizeof(float)));
+        PH_VOID(hipMalloc((void **)&d_fdir, nsave * sizeof(float)));
+        std::vector<float> host(nsave);
+        const long long kmax = (num_particles + chunk - 1) / chunk;
+        for (long long k = 0; k < kmax && rc == 0; k++) {
+            PH_VOID(hipMemset(d_fpos, 0xFF, nsave * sizeof(float)));    // all-ones = NaN (.cu:3527-3533)
+            PH_VOID(hipMemset(d_fdir, 0xFF, nsave * sizeof(float)));
+            const DumpDev dump{d_fpos, d_fdir, num_lightrays_save};
+            rc = launch_chunk(scene, vol, ray_tracing_algorithm, k * chunk, std::min(num_particles, (k + 1) * chunk),
+                              d_image, dump, nullptr, false);
+            if (rc) break;
+            PH_VOID(hipMemcpy(host.data(), d_fpos, nsave * sizeof(float), hipMemcpyDeviceToHost));
+            write_dump(lightray_position_save_path, "pos_", (int)k, host);
+            PH_VOID(hipMemcpy(host.data(), d_fdir, nsave * sizeof(float), hipMemcpyDeviceToHost));
+            write_dump(lightray_direction_save_path, "dir_", (int)k, host);
+        }
+    } else {
+        rc = photon_trace(scene, vol, ray_tracing_algorithm, 0, num_particles, d_image, nullptr, nullptr);
+    }
+    if (rc) {
+        fprintf(stderr, "photon: trace failed (%d); image left untouched\n", rc);
+        cleanup();
+        return;
+    }
+    PH_VOID(hipDeviceSynchronize());
+    PH_VOID(hipMemcpy(image_array, d_image, npix * sizeof(float), hipMemcpyDeviceToHost));     // .cu:3675
+#undef PH_VOID
+    cleanup();
+    if (verbose()) {
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("photon: %lld sources x %lld rays in %.3f s (%.2f Mrays/s incl. transfers)\n", num_particles, rps, s,
+               num_particles * rps / s * 1e-6);
+    }
+}

@@ -1,0 +1,204 @@
+"""Load libparallel_ray_tracing.so and bind its C-ABI (include/parallel_ray_tracing.h).
+
+``PhotonLibrary`` is a thin ctypes veneer: every method is one call into the HIP library.
+There is no Python or CPU fallback -- if the library is missing or a HIP call fails, you get an
+exception.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+from .ray_tracing import (RayTracingCall, bind_start_ray_tracing, camera_design_struct, element_data_struct,
+                          lightfield_source_struct, scattering_data_struct)
+
+# every symbol include/parallel_ray_tracing.h declares
+DECLARED_SYMBOLS = (
+    "start_ray_tracing", "photon_set_device", "photon_rand_table", "photon_volume_load_nrrd",
+    "photon_volume_from_density", "photon_volume_info", "photon_volume_download", "photon_volume_sample",
+    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_trace",
+    "photon_trace_volume_rays", "photon_version",
+)
+
+
+class photon_volume_info_t(ctypes.Structure):
+    _fields_ = [("min_bound", ctypes.c_float * 3), ("max_bound", ctypes.c_float * 3),
+                ("nx", ctypes.c_int), ("ny", ctypes.c_int), ("nz", ctypes.c_int),
+                ("grid_spacing", ctypes.c_float * 3), ("step_size", ctypes.c_float),
+                ("data_min", ctypes.c_float), ("interpolation", ctypes.c_int)]
+
+
+class photon_trace_stats_t(ctypes.Structure):
+    _fields_ = [("rays_launched", ctypes.c_uint64), ("rays_on_sensor", ctypes.c_uint64),
+                ("rk_iterations", ctypes.c_uint64), ("volume_samples", ctypes.c_uint64),
+                ("sensor_taps", ctypes.c_uint64), ("march_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class PhotonError(RuntimeError):
+    pass
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class PhotonLibrary:
+    def __init__(self, path: Optional[str] = None, build: bool = True):
+        if path is None:
+            path = os.environ.get("PHOTON_LIBRARY") or _build.LIB_PATH
+            if build and not os.path.exists(path):
+                _build.build_library()
+        if not os.path.exists(path):
+            raise PhotonError(f"{path} not found: build it with `python -m photon_amd.build` "
+                              "(there is no CPU fallback)")
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        self.start_ray_tracing = bind_start_ray_tracing(L)
+        L.photon_version.restype = ctypes.c_char_p
+        L.photon_set_device.argtypes = [ctypes.c_int]
+        L.photon_rand_table.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.photon_volume_load_nrrd.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.photon_volume_from_density.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                 ctypes.POINTER(ctypes.c_void_p)]
+        L.photon_volume_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(photon_volume_info_t)]
+        L.photon_volume_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.photon_volume_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.photon_volume_free.argtypes = [ctypes.c_void_p]
+        L.photon_volume_free.restype = None
+        L.photon_scene_create.argtypes = [
+            ctypes.c_float, ctypes.c_float, ctypes.POINTER(scattering_data_struct), ctypes.c_char_p,
+            ctypes.POINTER(lightfield_source_struct), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+            ctypes.c_void_p, ctypes.POINTER(element_data_struct), ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.POINTER(camera_design_struct), ctypes.c_float, ctypes.POINTER(ctypes.c_void_p)]
+        L.photon_scene_free.argtypes = [ctypes.c_void_p]
+        L.photon_scene_free.restype = None
+        L.photon_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(photon_trace_stats_t)]
+        L.photon_trace_volume_rays.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p]
+
+    # ---- helpers --------------------------------------------------------------------------
+    @staticmethod
+    def _check(rc: int, what: str):
+        if rc != 0:
+            raise PhotonError(f"{what} failed with code {rc} (see stderr)")
+
+    def version(self) -> str:
+        return self.lib.photon_version().decode()
+
+    def set_device(self, device: int):
+        self._check(self.lib.photon_set_device(int(device)), "photon_set_device")
+
+    def rand_table(self, n: int):
+        r1 = np.empty(n, np.float32)
+        r2 = np.empty(n, np.float32)
+        self._check(self.lib.photon_rand_table(n, _ptr(r1), _ptr(r2)), "photon_rand_table")
+        return r1, r2
+
+    # ---- the reference's entry point ----------------------------------------------------------
+    def render(self, call: RayTracingCall, image: Optional[np.ndarray] = None) -> np.ndarray:
+        """One start_ray_tracing call (host image in, host image out)."""
+        if image is None:
+            image = call.new_image()
+        call.invoke(self.start_ray_tracing, image)
+        return image
+
+    # ---- volumes ------------------------------------------------------------------------------
+    def volume_load_nrrd(self, path: str, interpolation: int = 1) -> "Volume":
+        h = ctypes.c_void_p()
+        self._check(self.lib.photon_volume_load_nrrd(path.encode(), int(interpolation), ctypes.byref(h)),
+                    "photon_volume_load_nrrd")
+        return Volume(self, h)
+
+    def volume_from_density(self, rho: np.ndarray, spacing, origin, interpolation: int = 1) -> "Volume":
+        """rho indexed [z, y, x] (x fastest), float32."""
+        rho = np.ascontiguousarray(rho, dtype=np.float32)
+        nz, ny, nx = rho.shape
+        sp = np.ascontiguousarray(spacing, dtype=np.float64)
+        og = np.ascontiguousarray(origin, dtype=np.float64)
+        h = ctypes.c_void_p()
+        self._check(self.lib.photon_volume_from_density(_ptr(rho), nx, ny, nz, _ptr(sp), _ptr(og), int(interpolation),
+                                                        ctypes.byref(h)), "photon_volume_from_density")
+        return Volume(self, h)
+
+    # ---- scenes -------------------------------------------------------------------------------
+    def scene_create(self, call: RayTracingCall) -> "Scene":
+        sd, ls, elems, centers, planes, sysidx, cam = call.pack()
+        h = ctypes.c_void_p()
+        rc = self.lib.photon_scene_create(
+            ctypes.c_float(call.lens_pitch), ctypes.c_float(call.image_distance), ctypes.byref(sd),
+            call.scattering_type.encode(), ctypes.byref(ls), int(call.lightray_number_per_particle),
+            ctypes.c_float(call.beam_wavelength), ctypes.c_float(call.aperture_f_number), len(call.elements),
+            _ptr(centers), elems, _ptr(planes), _ptr(sysidx), ctypes.byref(cam),
+            ctypes.c_float(call.ray_cone_pitch_ratio), ctypes.byref(h))
+        self._check(rc, "photon_scene_create")
+        return Scene(self, h, call)
+
+
+class Volume:
+    def __init__(self, lib: PhotonLibrary, handle):
+        self._lib, self.handle = lib, handle
+
+    def info(self) -> photon_volume_info_t:
+        i = photon_volume_info_t()
+        self._lib._check(self._lib.lib.photon_volume_info(self.handle, ctypes.byref(i)), "photon_volume_info")
+        return i
+
+    def download(self, coefficients: bool = False) -> np.ndarray:
+        i = self.info()
+        out = np.empty((i.nz, i.ny, i.nx, 4), np.float32)
+        self._lib._check(self._lib.lib.photon_volume_download(self.handle, int(coefficients), _ptr(out)),
+                         "photon_volume_download")
+        return out
+
+    def sample(self, coords: np.ndarray) -> np.ndarray:
+        c = np.ascontiguousarray(coords, dtype=np.float32).reshape(-1, 3)
+        out = np.empty((c.shape[0], 4), np.float32)
+        self._lib._check(self._lib.lib.photon_volume_sample(self.handle, c.shape[0], _ptr(c), _ptr(out)),
+                         "photon_volume_sample")
+        return out
+
+    def trace_rays(self, pos: np.ndarray, direction: np.ndarray, algorithm: int = 2):
+        p = np.array(pos, dtype=np.float32, order="C").reshape(-1, 3)
+        d = np.array(direction, dtype=np.float32, order="C").reshape(-1, 3)
+        steps = np.zeros(p.shape[0], np.int32)
+        self._lib._check(self._lib.lib.photon_trace_volume_rays(self.handle, int(algorithm), p.shape[0], _ptr(p),
+                                                                _ptr(d), _ptr(steps)), "photon_trace_volume_rays")
+        return p, d, steps
+
+    def free(self):
+        if self.handle:
+            self._lib.lib.photon_volume_free(self.handle)
+            self.handle = None
+
+
+class Scene:
+    def __init__(self, lib: PhotonLibrary, handle, call: RayTracingCall):
+        self._lib, self.handle, self.call = lib, handle, call
+
+    def trace(self, d_image_ptr: int, volume: Optional[Volume] = None, algorithm: int = 0, src_begin: int = 0,
+              src_end: Optional[int] = None, stream: int = 0, want_stats: bool = False):
+        """Accumulate into a DEVICE image (raw pointer, e.g. torch tensor .data_ptr())."""
+        if src_end is None:
+            src_end = self.call.num_sources
+        stats = photon_trace_stats_t() if want_stats else None
+        rc = self._lib.lib.photon_trace(self.handle, volume.handle if volume is not None else None, int(algorithm),
+                                        int(src_begin), int(src_end), ctypes.c_void_p(int(d_image_ptr)),
+                                        ctypes.c_void_p(int(stream)) if stream else None,
+                                        ctypes.byref(stats) if stats is not None else None)
+        self._lib._check(rc, "photon_trace")
+        return stats
+
+    def free(self):
+        if self.handle:
+            self._lib.lib.photon_scene_free(self.handle)
+            self.handle = None

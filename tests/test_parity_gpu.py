@@ -1,0 +1,310 @@
+"""GPU parity tests: the HIP library (through its C-ABI) against the CPU oracle.
+
+Bars (stated where used):
+  * integer / index / table data and every per-ray float quantity that is produced by IEEE
+    operations in a fixed order (volume texels, B-spline coefficients, sampler output, marched ray
+    position/direction, dumped rays): BIT-EXACT.
+  * sensor images: <= 1e-5 relative L2 (BASELINE.json north_star).  The only sources of difference
+    are the order of the f32 atomic adds and libm-vs-ocml erf() at 1e-16.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_fixture_call
+from photon_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+IMAGE_TOL = 1e-5
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    same = (bits(a) == bits(b)) | both_nan
+    assert same.all(), f"{what}: {np.count_nonzero(~same)} of {same.size} values differ; first at " \
+                       f"{np.argwhere(~same)[0]}: {a[~same][0]!r} vs {b[~same][0]!r}"
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side tables
+# ------------------------------------------------------------------------------------------------
+def test_rand_table_matches_glibc(photon, oracle):
+    r1, r2 = photon.rand_table(10000)
+    o1, o2 = oracle.rand_table(10000)
+    assert np.array_equal(r1, o1) and np.array_equal(r2, o2)
+
+
+# ------------------------------------------------------------------------------------------------
+# volume: build, prefilter, samplers, march -- all bit-exact
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def vol_pair(photon, oracle):
+    rng = np.random.default_rng(5)
+    n = (40, 36, 44)                                  # nz, ny, nx: deliberately unequal
+    z, y, x = np.meshgrid(*(np.linspace(-1, 1, k) for k in n), indexing="ij")
+    rho = (1.2 + 0.3 * np.exp(-(x ** 2 + 1.5 * y ** 2 + 0.7 * z ** 2) * 3) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    spacing = (310.0, 295.5, 402.25)
+    origin = (-6000.0, -5000.0, 400000.0)
+    out = {}
+    for interp in (1, 2):
+        out[interp] = (photon.volume_from_density(rho, spacing, origin, interp),
+                       oracle.volume_from_density(rho, spacing, origin, interp))
+    yield out
+    for g, o in out.values():
+        g.free()
+        o.free()
+
+
+@pytest.mark.parametrize("interp", [1, 2])
+def test_volume_build_bit_exact(vol_pair, interp):
+    g, o = vol_pair[interp]
+    gi, oi = g.info(), o.info()
+    for f in ("nx", "ny", "nz", "interpolation"):
+        assert getattr(gi, f) == getattr(oi, f)
+    for f in ("step_size", "data_min"):
+        assert np.float32(getattr(gi, f)).view(np.uint32) == np.float32(getattr(oi, f)).view(np.uint32), f
+    assert list(gi.min_bound) == list(oi.min_bound) and list(gi.max_bound) == list(oi.max_bound)
+    assert_bit_equal(g.download(False), o.download(False), "gradient texels")
+    if interp == 2:
+        assert_bit_equal(g.download(True), o.download(True), "B-spline coefficients")
+
+
+def test_sample_nrrd_volume_bit_exact(photon, oracle, golden_dir):
+    path = os.path.join(golden_dir, "sample-density.nrrd")
+    for interp in (1, 2):
+        g, o = photon.volume_load_nrrd(path, interp), oracle.volume_load_nrrd(path, interp)
+        assert_bit_equal(g.download(interp == 2), o.download(interp == 2), f"sample volume interp {interp}")
+        assert g.info().data_min == o.info().data_min
+        g.free()
+        o.free()
+
+
+@pytest.mark.parametrize("interp", [1, 2])
+def test_sampler_bit_exact(vol_pair, interp):
+    g, o = vol_pair[interp]
+    i = g.info()
+    rng = np.random.default_rng(11)
+    n = 50000
+    coords = np.stack([rng.uniform(-2, i.nx + 2, n), rng.uniform(-2, i.ny + 2, n), rng.uniform(-2, i.nz + 2, n)], 1)
+    coords[:64] = np.round(coords[:64])              # texel centres / edges
+    coords[64:128] = np.floor(coords[64:128]) + 0.5
+    assert_bit_equal(g.sample(coords), o.sample(coords), f"sampler interp {interp}")
+
+
+@pytest.mark.parametrize("algorithm", [1, 2])
+@pytest.mark.parametrize("interp", [1, 2])
+def test_march_bit_exact(vol_pair, interp, algorithm):
+    g, o = vol_pair[interp]
+    i = g.info()
+    rng = np.random.default_rng(3)
+    n = 6000
+    lo, hi = np.array(i.min_bound), np.array(i.max_bound)
+    pos = np.stack([rng.uniform(lo[a] - 0.1 * (hi[a] - lo[a]), hi[a] + 0.1 * (hi[a] - lo[a]), n) for a in range(3)], 1)
+    pos[:, 2] = hi[2] + 5000.0                       # start above the volume, head down (-z) ...
+    d = np.stack([rng.normal(0, 0.05, n), rng.normal(0, 0.05, n), -np.ones(n)], 1)
+    pos[:500] = np.stack([rng.uniform(lo[a], hi[a], 500) for a in range(3)], 1)      # ... some start inside
+    d[500:700, 2] = 1.0                              # ... some fly away (miss: must come back untouched)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    gp, gd, gs = g.trace_rays(pos, d, algorithm)
+    op, od, os_ = o.trace_rays(pos, d, algorithm)
+    assert np.array_equal(gs, os_), "iteration counts differ"
+    assert gs.max() > 10
+    assert_bit_equal(gp, op, "marched positions")
+    assert_bit_equal(gd, od, "marched directions")
+
+
+# ------------------------------------------------------------------------------------------------
+# full pipeline through start_ray_tracing
+# ------------------------------------------------------------------------------------------------
+def _render_both(photon, oracle, call, interp=1, monkeypatch=None):
+    if monkeypatch is not None:
+        monkeypatch.setenv("PHOTON_INTERP", "cubic" if interp == 2 else "linear")
+    g = photon.render(call)
+    o, st = oracle.render(call, interpolation=interp)
+    return g, o, st
+
+
+@pytest.mark.parametrize("case", ["piv", "bos_im1", "bos_im2"])
+def test_reference_sample_inputs(photon, oracle, case, monkeypatch):
+    """Inputs captured from the reference's own marshalling code for its shipped samples."""
+    call = load_fixture_call(case)
+    g, o, st = _render_both(photon, oracle, call, 1, monkeypatch)
+    assert st.rays_on_sensor > 0 and o.sum() > 0
+    assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+
+
+def test_c0_plumbing(photon, oracle):
+    call = scenes.config("C0")
+    g, o, st = _render_both(photon, oracle, call)
+    assert o.sum() > 0
+    assert rel_l2(g, o) <= IMAGE_TOL
+
+
+def test_c2_piv_mie_small(photon, oracle):
+    call = scenes.piv_scene(n_particles=40, rays_per_source=2500, mie=True)
+    g, o, st = _render_both(photon, oracle, call)
+    assert st.rays_on_sensor > 1000
+    assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+
+
+def test_piv_polydisperse_mie(photon, oracle):
+    call = scenes.piv_scene(n_particles=300, rays_per_source=300, mie=True, polydisperse=True, seed=4)
+    g, o, _ = _render_both(photon, oracle, call)
+    assert rel_l2(g, o) <= IMAGE_TOL
+
+
+@pytest.fixture(scope="module")
+def small_volume_file(workdir):
+    rho, sp, org = scenes.bos_volume(48)
+    return scenes.write_nrrd(os.path.join(workdir, "bos48.nrrd"), rho, sp, org)
+
+
+@pytest.mark.parametrize("interp", [1, 2])
+@pytest.mark.parametrize("algorithm", [1, 2])
+def test_c3_bos_volume_small(photon, oracle, small_volume_file, interp, algorithm, monkeypatch):
+    call = scenes.bos_scene(n_dots=12, points_per_dot=30, rays_per_source=120, density_grad_filename=small_volume_file,
+                            ray_tracing_algorithm=algorithm)
+    g, o, st = _render_both(photon, oracle, call, interp, monkeypatch)
+    assert st.rk_iterations > 40 * call.num_rays          # rays really crossed the 48^3 volume
+    assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+    # and the volume matters: the undisturbed image differs
+    ref = photon.render(scenes.bos_scene(n_dots=12, points_per_dot=30, rays_per_source=120))
+    assert rel_l2(g, ref) > 1e-3
+
+
+def test_c5_piv_with_volume_small(photon, oracle, small_volume_file, monkeypatch):
+    call = scenes.piv_scene(n_particles=400, rays_per_source=40, mie=True, polydisperse=True,
+                            density_grad_filename=small_volume_file, field_half_width=3.0e4, sort_by_tile=True)
+    g, o, st = _render_both(photon, oracle, call, 2, monkeypatch)
+    assert st.rk_iterations > 0
+    assert rel_l2(g, o) <= IMAGE_TOL
+
+
+@pytest.mark.parametrize("lens_model,etype", [("thin-lens", "t"), ("apparent", "n"), ("general", "a")])
+def test_other_element_types(photon, oracle, lens_model, etype):
+    call = scenes.bos_scene(n_dots=8, points_per_dot=20, rays_per_source=64, lens_model=lens_model)
+    if etype == "a":                                   # aperture stop: any other element_type char
+        call.elements[0]["element_type"] = "a"
+    else:
+        assert call.elements[0]["element_type"] == etype
+    g, o, st = _render_both(photon, oracle, call)
+    if etype != "a":
+        assert st.rays_on_sensor > 0
+    assert rel_l2(g, o) <= IMAGE_TOL if o.any() else not g.any()
+
+
+def test_single_ray_per_source_is_chief_ray(photon, oracle):
+    call = scenes.bos_scene(n_dots=30, points_per_dot=10, rays_per_source=1)
+    g, o, _ = _render_both(photon, oracle, call)
+    assert rel_l2(g, o) <= IMAGE_TOL
+
+
+def test_image_is_accumulated_not_overwritten(photon):
+    call = scenes.piv_scene(n_particles=20, rays_per_source=200, mie=False)
+    first = photon.render(call)
+    assert first.any()
+    second = photon.render(call, first.copy())          # in/out buffer: renders on top of `first`
+    assert rel_l2(second, 2.0 * first.astype(np.float64)) <= 1e-5
+    base = np.zeros(call.image_shape, np.float32)
+    base[0, 0] = 1000.0                                 # a pixel no ray reaches keeps its value
+    third = photon.render(call, base.copy())
+    assert third[0, 0] == 1000.0 + first[0, 0]
+
+
+def test_empty_and_ragged_inputs(photon, oracle):
+    # zero sources: nothing happens, image untouched
+    call = scenes.piv_scene(n_particles=0, rays_per_source=10, mie=False)
+    img = np.full(call.image_shape, 3.0, np.float32)
+    assert np.array_equal(photon.render(call, img.copy()), img)
+    # ray count that is not a multiple of the wave / workgroup size, more sources than one chunk
+    call = scenes.piv_scene(n_particles=137, rays_per_source=77, mie=False, seed=9)
+    call.source_point_number = 50
+    g, o, _ = _render_both(photon, oracle, call)
+    assert rel_l2(g, o) <= IMAGE_TOL
+
+
+def test_ray_dumps_bit_exact(photon, oracle, small_volume_file, tmp_path):
+    call = scenes.bos_scene(n_dots=3, points_per_dot=20, rays_per_source=50, density_grad_filename=small_volume_file)
+    call.source_point_number = 25                      # 60 sources -> 3 chunks -> 3 file pairs
+    call.save_lightrays = True
+    call.num_lightrays_save = 25 * 50
+    outs = {}
+    for tag, run in (("gpu", lambda c: photon.render(c)), ("cpu", lambda c: oracle.render(c)[0])):
+        pdir, ddir = tmp_path / f"{tag}_pos", tmp_path / f"{tag}_dir"
+        pdir.mkdir()
+        ddir.mkdir()
+        call.lightray_position_save_path, call.lightray_direction_save_path = str(pdir), str(ddir)
+        run(call)
+        outs[tag] = (pdir, ddir)
+    for k in range(3):
+        for which, prefix in ((0, "pos_"), (1, "dir_")):
+            a = np.fromfile(outs["gpu"][which] / f"{prefix}{k:04d}.bin", np.float32)
+            b = np.fromfile(outs["cpu"][which] / f"{prefix}{k:04d}.bin", np.float32)
+            assert a.size == b.size == 25 * 50 * 3
+            assert_bit_equal(a, b, f"{prefix}{k:04d}.bin")
+    assert np.isfinite(np.fromfile(outs["gpu"][0] / "pos_0000.bin", np.float32)).any()
+
+
+def test_errors_leave_image_untouched(photon, small_volume_file, capfd):
+    call = scenes.bos_scene(n_dots=2, points_per_dot=5, rays_per_source=8, density_grad_filename=small_volume_file)
+    img = np.full(call.image_shape, 1.5, np.float32)
+    call.ray_tracing_algorithm = 3                     # rk45: not built
+    assert np.array_equal(photon.render(call, img.copy()), img)
+    call.ray_tracing_algorithm = 2
+    call.density_grad_filename = "/nonexistent/volume.nrrd"
+    assert np.array_equal(photon.render(call, img.copy()), img)
+    assert "photon:" in capfd.readouterr().err
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE-size properties (no oracle: size-independent invariants)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_c3_properties(photon, workdir, monkeypatch):
+    """1e7 rays through the 256^3 volume (tricubic RK4): (1) sharding the sources in two and
+    summing reproduces the single-pass image (what the multi-GPU path relies on); (2) a uniform
+    volume deflects nothing: the image equals the no-volume image; (3) counters add up."""
+    import torch
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    call = scenes.config("C3", workdir)
+    assert call.num_rays == 10_000_000
+    scene = photon.scene_create(call)
+    vol = photon.volume_load_nrrd(call.density_grad_filename, 2)
+    H, W = call.image_shape
+    full = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    st = scene.trace(full.data_ptr(), vol, 2, want_stats=True)
+    assert st.rays_launched == call.num_rays
+    assert st.rk_iterations >= 250 * call.num_rays and st.volume_samples >= 3 * st.rk_iterations
+    assert st.rays_on_sensor == call.num_rays and st.sensor_taps > 10 * call.num_rays
+    halves = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    mid = call.num_sources // 2 + 7
+    scene.trace(halves.data_ptr(), vol, 2, 0, mid)
+    scene.trace(halves.data_ptr(), vol, 2, mid, call.num_sources)
+    torch.cuda.synchronize()
+    assert rel_l2(halves.cpu().numpy(), full.cpu().numpy()) <= IMAGE_TOL
+    # uniform density -> zero gradient -> straight rays
+    rho = np.full((32, 32, 32), 1.225, np.float32)
+    _, sp, org = scenes.bos_volume(32)
+    uni = photon.volume_from_density(rho, sp, org, 2)
+    a = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    b = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    scene.trace(a.data_ptr(), uni, 2, 0, 2000)
+    scene.trace(b.data_ptr(), None, 0, 0, 2000)
+    torch.cuda.synchronize()
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-3      # f32 world-transform round trip only
+    scene.free()
+    vol.free()
+    uni.free()
