@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py - Mrays/s of the ray-tracing hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config C3 of BASELINE.json): BOS render, 2e4 light-field sources x
+500 rays = 1e7 rays PER GPU through a 256^3 density-gradient volume, RK4 with the tricubic
+B-spline sampler, thick-lens camera, erf splat (D = 3 px) onto a 1024^2 sensor.  One "step" = one
+full render of the rank's sources with everything (sources, tables, volume, image) already
+resident in HBM: zero the private image, trace, and -- for N > 1 -- sum-reduce the image onto
+rank 0 (RCCL).  Weak scaling: every rank renders its own 1e7-ray shard of an N x 1e7-ray job.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      algorithmic bytes of the march kernel / its HIP-event duration vs the HBM peak
+  cpu_baseline  the CPU oracle (scalar C++ restatement, OpenMP) timed on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+TEXELS_PER_SAMPLE = {1: 8, 2: 64}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--interp", choices=["cubic", "linear"], default="cubic")
+    ap.add_argument("--volume", type=int, default=256, help="grid points per axis of the density volume")
+    ap.add_argument("--dots", type=int, default=200, help="BOS dots per GPU (x100 sources x500 rays)")
+    ap.add_argument("--rays-per-source", type=int, default=500)
+    ap.add_argument("--cpu-sample-rays", type=int, default=50000, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--check", action="store_true", help="also verify a slice of the image against the oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source):
+    """Time the oracle's ray loop (volume prebuilt, like the GPU side) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle_lib import Oracle
+    o = Oracle()
+    n_src = max(1, sample_rays // rays_per_source)
+    call = call_factory(n_sources=n_src)
+    vol = o.volume_load_nrrd(volume_path, interp)
+    t0 = time.perf_counter()
+    _, st = o.render_with_volume(call, vol)
+    dt = time.perf_counter() - t0
+    vol.free()
+    rays = n_src * rays_per_source
+    return {"value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": o.num_threads(), "kind": "port",
+            "sample": f"{rays} rays ({n_src} sources x {rays_per_source}) of the same scene and volume, "
+                      f"ray loop only (volume prebuilt), {dt:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from photon_amd import scenes
+    from photon_amd.library import PhotonLibrary
+    from photon_amd.sharding import reduce_image
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    interp = 2 if args.interp == "cubic" else 1
+
+    # ---- synthetic inputs (host) -> resident in HBM ------------------------------------------
+    workdir = os.environ.get("PHOTON_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "photon_bench")
+    os.makedirs(workdir, exist_ok=True)
+    vol_path = os.path.join(workdir, f"bos_{args.volume}.nrrd")
+    if rank == 0 and not os.path.exists(vol_path):
+        rho, sp, org = scenes.bos_volume(args.volume)
+        scenes.write_nrrd(vol_path + ".tmp", rho, sp, org)
+        os.replace(vol_path + ".tmp", vol_path)
+    if world > 1:
+        dist.barrier()
+
+    def make_call(seed=1 + rank, n_dots=args.dots, n_sources=None):
+        c = scenes.bos_scene(n_dots=n_dots, points_per_dot=100, rays_per_source=args.rays_per_source,
+                             density_grad_filename=vol_path, seed=seed)
+        if n_sources is not None:       # leading slice of the same source list
+            for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+                setattr(c, f, getattr(c, f)[:n_sources])
+        return c
+
+    lib = PhotonLibrary()
+    call = make_call()
+    scene = lib.scene_create(call)
+    t0 = time.perf_counter()
+    volume = lib.volume_load_nrrd(vol_path, interp)
+    torch.cuda.synchronize()
+    volume_build_s = time.perf_counter() - t0
+    H, W = call.image_shape
+    image = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(want_stats):
+        image.zero_()
+        st = scene.trace(image.data_ptr(), volume, 2, 0, call.num_sources, stream=stream, want_stats=want_stats)
+        reduce_image(image, 0)
+        return st
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    march_ms, iters, samples, taps, on_sensor = 0.0, 0, 0, 0, 0
+    for _ in range(args.steps):
+        st = step(True)               # HIP events bracket the march kernel on the launch stream
+        march_ms += st.march_ms
+        iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rays_per_gpu = call.num_rays
+    total_rays = rays_per_gpu * world
+    value = total_rays * args.steps / elapsed * 1e-6
+
+    # ---- roofline of the dominant kernel (march_kernel<rk4, interp>) ---------------------------
+    s_bar = iters / rays_per_gpu
+    a_bar = taps / rays_per_gpu
+    bytes_per_ray = s_bar * 3 * TEXELS_PER_SAMPLE[interp] * 16 + a_bar * 8 + 40
+    march_ms_avg = march_ms / args.steps
+    achieved = rays_per_gpu * bytes_per_ray / (march_ms_avg * 1e-3) * 1e-9 if march_ms_avg > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")      # written from rocprofv3 --pmc runs
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                traffic = json.load(f).get(f"march_{args.interp}_{args.volume}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": f"march_kernel<rk4,{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
+                "bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
+                "sensor_taps_per_ray": round(a_bar, 2),
+                "compulsory_bytes": int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources)}
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if args.cpu_sample_rays > 0:
+            cpu = cpu_baseline(lambda n_sources: make_call(seed=1, n_sources=n_sources), vol_path, interp,
+                               args.cpu_sample_rays, args.rays_per_source)
+        out = {
+            "metric": "Mrays/sec, 1e7-ray 256^3 BOS render (HBM GB/s %peak under roofline)",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: BOS, {rays_per_gpu} rays/GPU ({call.num_sources} sources x "
+                                   f"{args.rays_per_source}), {args.volume}^3 volume, RK4, {args.interp} sampler, "
+                                   f"erf splat D=3, 1024^2 sensor",
+                       "rays_total": total_rays, "parallelism": f"sources sharded x{world}, RCCL sum-reduce of the image"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "volume_build_s": round(volume_build_s, 3), "rays_on_sensor": int(on_sensor),
+        }
+        if args.check:
+            out["check"] = check_against_oracle(lib, make_call, vol_path, interp)
+        print(json.dumps(out), flush=True)
+    scene.free()
+    volume.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def check_against_oracle(lib, make_call, vol_path, interp):
+    """Parity spot check inside the bench: 40 sources through both paths."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle_lib import Oracle
+    o = Oracle()
+    call = make_call(seed=1, n_sources=40)
+    os.environ["PHOTON_INTERP"] = "cubic" if interp == 2 else "linear"
+    g = lib.render(call).astype(np.float64)
+    c, _ = o.render(call, interpolation=interp)
+    return {"rel_l2": float(np.linalg.norm(g - c) / np.linalg.norm(c)), "sources": 40}
+
+
+if __name__ == "__main__":
+    main()

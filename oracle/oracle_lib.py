@@ -1,0 +1,180 @@
+"""ctypes access to the CPU parity oracle (oracle/libphoton_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under photon_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file: oracle/)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from photon_amd.library import photon_volume_info_t  # noqa: E402  (struct layout only)
+from photon_amd.ray_tracing import RayTracingCall, bind_start_ray_tracing, element_from_dict  # noqa: E402
+
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libphoton_oracle.so")
+
+
+class oracle_stats_t(ctypes.Structure):
+    _fields_ = [("rays_launched", ctypes.c_uint64), ("rays_on_sensor", ctypes.c_uint64),
+                ("rk_iterations", ctypes.c_uint64), ("volume_samples", ctypes.c_uint64),
+                ("sensor_taps", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def build_oracle(force: bool = False) -> str:
+    src = os.path.join(ORACLE_DIR, "photon_oracle.cpp")
+    stale = (not os.path.exists(ORACLE_SO)) or any(
+        os.path.getmtime(p) > os.path.getmtime(ORACLE_SO)
+        for p in (src, os.path.join(ROOT, "include", "parallel_ray_tracing.h"),
+                  os.path.join(ROOT, "include", "photon_det_math.h")))
+    if force or stale:
+        subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+    return ORACLE_SO
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = ctypes.CDLL(build_oracle())
+        L = self.lib
+        self._start = bind_start_ray_tracing(L, "oracle_start_ray_tracing",
+                                             [ctypes.c_int, ctypes.c_int, ctypes.POINTER(oracle_stats_t)])
+        self._render_vol = bind_start_ray_tracing(L, "oracle_render_with_volume",
+                                                  [ctypes.c_void_p, ctypes.POINTER(oracle_stats_t)])
+        L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_volume_from_density.restype = ctypes.c_void_p
+        L.oracle_volume_from_density.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.oracle_volume_load_nrrd.restype = ctypes.c_void_p
+        L.oracle_volume_load_nrrd.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        L.oracle_volume_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(photon_volume_info_t)]
+        L.oracle_volume_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.oracle_volume_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_trace_volume_rays.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_volume_free.argtypes = [ctypes.c_void_p]
+        L.oracle_det_eval.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_ray_sphere_intersection.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
+                                                     ctypes.c_void_p, ctypes.c_char, ctypes.c_void_p]
+        L.oracle_axis_distance.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
+        L.oracle_single_element.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
+
+    # ---- full pipeline --------------------------------------------------------------------
+    def render(self, call: RayTracingCall, image=None, interpolation: int = 1, tex_frac_bits: int = 0):
+        if image is None:
+            image = call.new_image()
+        st = oracle_stats_t()
+        call.invoke(self._start, image, extra=(int(interpolation), int(tex_frac_bits), ctypes.byref(st)))
+        return image, st
+
+    def render_with_volume(self, call: RayTracingCall, volume, image=None):
+        """Ray loop only, on a prebuilt OracleVolume (or None)."""
+        if image is None:
+            image = call.new_image()
+        st = oracle_stats_t()
+        call.invoke(self._render_vol, image, extra=(volume.handle if volume is not None else None, ctypes.byref(st)))
+        return image, st
+
+    def num_threads(self) -> int:
+        return int(self.lib.oracle_num_threads())
+
+    def rand_table(self, n):
+        r1, r2 = np.empty(n, np.float32), np.empty(n, np.float32)
+        self.lib.oracle_rand_table(n, _p(r1), _p(r2))
+        return r1, r2
+
+    def det_eval(self, fn: int, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self.lib.oracle_det_eval(fn, x.size, _p(x), _p(y))
+        return y
+
+    # ---- volume ---------------------------------------------------------------------------
+    def volume_from_density(self, rho, spacing, origin, interpolation=1, tex_frac_bits=0):
+        rho = np.ascontiguousarray(rho, dtype=np.float32)
+        nz, ny, nx = rho.shape
+        sp = np.ascontiguousarray(spacing, dtype=np.float64)
+        og = np.ascontiguousarray(origin, dtype=np.float64)
+        h = self.lib.oracle_volume_from_density(_p(rho), nx, ny, nz, _p(sp), _p(og), interpolation, tex_frac_bits)
+        return OracleVolume(self, h)
+
+    def volume_load_nrrd(self, path, interpolation=1, tex_frac_bits=0):
+        h = self.lib.oracle_volume_load_nrrd(path.encode(), interpolation, tex_frac_bits)
+        assert h, f"oracle could not read {path}"
+        return OracleVolume(self, h)
+
+    # ---- optics ---------------------------------------------------------------------------
+    def ray_sphere_intersection(self, center, R, direction, pos, surface: str):
+        d = np.ascontiguousarray(direction, np.float32)
+        p = np.ascontiguousarray(pos, np.float32)
+        c = np.ascontiguousarray(center, np.float32)
+        out = np.empty_like(p)
+        self.lib.oracle_ray_sphere_intersection(p.shape[0], _p(c), float(R), _p(d), _p(p), surface.encode(), _p(out))
+        return out
+
+    def axis_distance(self, pts, center, plane):
+        pts = np.ascontiguousarray(pts, np.float32)
+        c = np.ascontiguousarray(center, np.float32)
+        pl = np.ascontiguousarray(plane, np.float32)
+        out = np.empty(pts.shape[0], np.float32)
+        self.lib.oracle_axis_distance(pts.shape[0], _p(pts), _p(c), _p(pl), _p(out))
+        return out
+
+    def single_element(self, element: dict, center, plane, pos, direction, wavelength, radiance):
+        e = element_from_dict(element)
+        p = np.array(pos, np.float32, order="C")
+        d = np.array(direction, np.float32, order="C")
+        r = np.array(radiance, np.float64, order="C")
+        c = np.ascontiguousarray(center, np.float32)
+        pl = np.ascontiguousarray(plane, np.float32)
+        self.lib.oracle_single_element(p.shape[0], ctypes.byref(e), _p(c), _p(pl), _p(p), _p(d), float(wavelength), _p(r))
+        return p, d, r
+
+
+class OracleVolume:
+    def __init__(self, o: Oracle, handle):
+        self._o, self.handle = o, ctypes.c_void_p(handle)
+
+    def info(self):
+        i = photon_volume_info_t()
+        self._o.lib.oracle_volume_info(self.handle, ctypes.byref(i))
+        return i
+
+    def download(self, coefficients=False):
+        i = self.info()
+        out = np.empty((i.nz, i.ny, i.nx, 4), np.float32)
+        self._o.lib.oracle_volume_download(self.handle, int(coefficients), _p(out))
+        return out
+
+    def sample(self, coords):
+        c = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
+        out = np.empty((c.shape[0], 4), np.float32)
+        self._o.lib.oracle_volume_sample(self.handle, c.shape[0], _p(c), _p(out))
+        return out
+
+    def trace_rays(self, pos, direction, algorithm=2):
+        p = np.array(pos, np.float32, order="C").reshape(-1, 3)
+        d = np.array(direction, np.float32, order="C").reshape(-1, 3)
+        steps = np.zeros(p.shape[0], np.int32)
+        self._o.lib.oracle_trace_volume_rays(self.handle, int(algorithm), p.shape[0], _p(p), _p(d), _p(steps))
+        return p, d, steps
+
+    def free(self):
+        if self.handle:
+            self._o.lib.oracle_volume_free(self.handle)
+            self.handle = None

@@ -1021,40 +1021,10 @@ struct oracle_stats_t {
     uint64_t rays_launched, rays_on_sensor, rk_iterations, volume_samples, sensor_taps;
 };
 
-// The reference's start_ray_tracing (parallel_ray_tracing.cu:3078-3775) on the CPU, plus two
-// trailing knobs the reference hard-codes: interpolation (1 linear = reference, 2 cubic) and
-// tex_frac_bits (0 exact, 8 = NVIDIA texture-unit weights).  stats may be NULL.
-void oracle_start_ray_tracing(float lens_pitch, float image_distance, scattering_data_t *scattering_data_p,
-                              char *scattering_type_str, lightfield_source_t *lightfield_source_p,
-                              int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
-                              int num_elements, double (*element_center)[3], element_data_t *element_data_p,
-                              double (*element_plane_parameters)[4], int *element_system_index,
-                              camera_design_t *camera_design_p, float *image_array,
-                              bool simulate_density_gradients, char *density_grad_filename, bool save_lightrays,
-                              char *lightray_position_save_path, char *lightray_direction_save_path,
-                              int num_lightrays_save, int ray_tracing_algorithm, bool add_pos_noise,
-                              float pos_noise_std, bool add_ngrad_noise, float ngrad_noise_std,
-                              float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
-                              int num_intermediate_positions_save, int interpolation, int tex_frac_bits,
-                              oracle_stats_t *stats) {
-    (void)add_pos_noise; (void)pos_noise_std; (void)add_ngrad_noise; (void)ngrad_noise_std;
-    (void)save_intermediate_ray_data; (void)num_intermediate_positions_save;
-    Scene sc;
-    build_scene(sc, lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
-                lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
-                element_data_p, element_plane_parameters, element_system_index, camera_design_p,
-                ray_cone_pitch_ratio);
-    Volume vol;
-    const Volume *volp = nullptr;
-    if (simulate_density_gradients) {
-        std::vector<float> rho; int dims[3]; double sp[3], org[3];
-        if (!read_nrrd(density_grad_filename, rho, dims, sp, org)) {
-            fprintf(stderr, "oracle: cannot read NRRD '%s'\n", density_grad_filename);
-            return;
-        }
-        setup_volume(vol, rho.data(), dims[0], dims[1], dims[2], sp, org, interpolation, tex_frac_bits);
-        volp = &vol;
-    }
+// Shared body: the launch loop of parallel_ray_tracing.cu:3366-3675 on the CPU.
+static void render_core(Scene &sc, const Volume *volp, float *image_array, bool save_lightrays,
+                        char *lightray_position_save_path, char *lightray_direction_save_path,
+                        int num_lightrays_save, int ray_tracing_algorithm, oracle_stats_t *stats) {
     const int W = sc.cam.x_pixel_number, H = sc.cam.y_pixel_number;
     const int64_t num_particles = sc.ls.num_particles;
     int64_t chunk = sc.ls.source_point_number;                          // .cu:3366-3372
@@ -1078,29 +1048,28 @@ void oracle_start_ray_tracing(float lens_pitch, float image_distance, scattering
             fpos.assign(num_lightrays_save, mk3(NANF, NANF, NANF));
             fdir.assign(num_lightrays_save, mk3(NANF, NANF, NANF));
         }
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int64_t lp = 0; lp < chunk; lp++) {
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t gid = 0; gid < num_rays; gid++) {                  // one iteration = one GPU thread
             int tid = 0;
 #ifdef _OPENMP
             tid = omp_get_thread_num();
 #endif
+            const int64_t lp = gid / rps;
+            const int lr = (int)(gid % rps);
             const int64_t source = n_min + lp;
             if (source >= num_particles) continue;                      // .cu:1967
-            for (int lr = 0; lr < rps; lr++) {
-                const int64_t gid = lr + lp * rps;
-                if (gid >= num_rays) continue;
-                RayOut out{mk3(NANF, NANF, NANF), mk3(NANF, NANF, NANF)};
-                const bool dump = save_lightrays && gid < num_lightrays_save;
-                trace_one(sc, volp, ray_tracing_algorithm, source, lr, imgs[tid], mcs[tid],
-                          dump ? &out : nullptr, on_sensor[tid]);
-                if (dump) { fpos[gid] = out.pos; fdir[gid] = out.dir; }
-            }
+            RayOut out{mk3(NANF, NANF, NANF), mk3(NANF, NANF, NANF)};
+            const bool dump = save_lightrays && gid < num_lightrays_save;
+            trace_one(sc, volp, ray_tracing_algorithm, source, lr, imgs[tid], mcs[tid], dump ? &out : nullptr,
+                      on_sensor[tid]);
+            if (dump) { fpos[gid] = out.pos; fdir[gid] = out.dir; }
         }
         if (save_lightrays) {
             write_dump(lightray_position_save_path, "pos_", (int)k, fpos);
             write_dump(lightray_direction_save_path, "dir_", (int)k, fdir);
         }
     }
+#pragma omp parallel for schedule(static)
     for (size_t p = 0; p < (size_t)W * H; p++) {
         double s = 0;
         for (int t = 0; t < nthreads; t++) s += imgs[t].acc[p];
@@ -1116,6 +1085,66 @@ void oracle_start_ray_tracing(float lens_pitch, float image_distance, scattering
             stats->sensor_taps += imgs[t].taps;
         }
     }
+}
+
+// The reference's start_ray_tracing (parallel_ray_tracing.cu:3078-3775) on the CPU, plus two
+// trailing knobs the reference hard-codes: interpolation (1 linear = reference, 2 cubic) and
+// tex_frac_bits (0 exact, 8 = NVIDIA texture-unit weights).  stats may be NULL.
+void oracle_start_ray_tracing(float lens_pitch, float image_distance, scattering_data_t *scattering_data_p,
+                              char *scattering_type_str, lightfield_source_t *lightfield_source_p,
+                              int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
+                              int num_elements, double (*element_center)[3], element_data_t *element_data_p,
+                              double (*element_plane_parameters)[4], int *element_system_index,
+                              camera_design_t *camera_design_p, float *image_array,
+                              bool simulate_density_gradients, char *density_grad_filename, bool save_lightrays,
+                              char *lightray_position_save_path, char *lightray_direction_save_path,
+                              int num_lightrays_save, int ray_tracing_algorithm, bool add_pos_noise,
+                              float pos_noise_std, bool add_ngrad_noise, float ngrad_noise_std,
+                              float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
+                              int num_intermediate_positions_save, int interpolation, int tex_frac_bits,
+                              oracle_stats_t *stats) {
+    Scene sc;
+    build_scene(sc, lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
+                lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                element_data_p, element_plane_parameters, element_system_index, camera_design_p,
+                ray_cone_pitch_ratio);
+    Volume vol;
+    const Volume *volp = nullptr;
+    if (simulate_density_gradients) {
+        std::vector<float> rho; int dims[3]; double sp[3], org[3];
+        if (!read_nrrd(density_grad_filename, rho, dims, sp, org)) {
+            fprintf(stderr, "oracle: cannot read NRRD '%s'\n", density_grad_filename);
+            return;
+        }
+        setup_volume(vol, rho.data(), dims[0], dims[1], dims[2], sp, org, interpolation, tex_frac_bits);
+        volp = &vol;
+    }
+    render_core(sc, volp, image_array, save_lightrays, lightray_position_save_path, lightray_direction_save_path,
+                num_lightrays_save, ray_tracing_algorithm, stats);
+}
+
+// Same, with a volume built beforehand by oracle_volume_* (NULL = no density gradients): lets the
+// CPU baseline time the ray loop without the volume build, like photon_trace on the GPU side.
+void oracle_render_with_volume(float lens_pitch, float image_distance, scattering_data_t *scattering_data_p,
+                               char *scattering_type_str, lightfield_source_t *lightfield_source_p,
+                               int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
+                               int num_elements, double (*element_center)[3], element_data_t *element_data_p,
+                               double (*element_plane_parameters)[4], int *element_system_index,
+                               camera_design_t *camera_design_p, float *image_array,
+                               bool simulate_density_gradients, char *density_grad_filename, bool save_lightrays,
+                               char *lightray_position_save_path, char *lightray_direction_save_path,
+                               int num_lightrays_save, int ray_tracing_algorithm, bool add_pos_noise,
+                               float pos_noise_std, bool add_ngrad_noise, float ngrad_noise_std,
+                               float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
+                               int num_intermediate_positions_save, void *volume, oracle_stats_t *stats) {
+    Scene sc;
+    build_scene(sc, lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
+                lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                element_data_p, element_plane_parameters, element_system_index, camera_design_p,
+                ray_cone_pitch_ratio);
+    render_core(sc, simulate_density_gradients ? static_cast<const Volume *>(volume) : nullptr, image_array,
+                save_lightrays, lightray_position_save_path, lightray_direction_save_path, num_lightrays_save,
+                ray_tracing_algorithm, stats);
 }
 
 void oracle_rand_table(int n, float *r1, float *r2) { rand_table(n, r1, r2); }

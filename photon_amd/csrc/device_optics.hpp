@@ -236,8 +236,11 @@ __device__ __forceinline__ Ray optical_system(const SceneDev &sc, Ray ray) {
 // Gaussian-spot splat: I0*pi/32 * d_erf(col) * d_erf(row) over the pixels within
 // render_fraction*D of the centroid (.cu:1477-1540 / :1660-1730).  The x and y erf differences
 // depend on col resp. row only, so they are evaluated once per column / per (column,row) -- the
-// products are the reference's, term for term.  One global_atomic_add_f32 per rendered pixel.
-__device__ __forceinline__ int erf_splat(float *image, int W, int H, float d_x, float d_y, double radiance,
+// products are the reference's, term for term.  Each rendered pixel receives the reference's f32
+// increment; the running sum is kept in f64 (one global_atomic_add_f64): the reference's
+// atomicAdd(float) in arbitrary order loses up to N*2^-25 relative on a pixel that receives N
+// near-identical increments (BOS dots: N ~ 1e4), far above the 1e-5 parity bar.
+__device__ __forceinline__ int erf_splat(double *image, int W, int H, float d_x, float d_y, double radiance,
                                          f3 dir, float D, float render_fraction) {
     const double pi = 3.141592653589793;
     const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
@@ -259,7 +262,7 @@ __device__ __forceinline__ int erf_splat(float *image, int W, int H, float d_x, 
             if (!(row >= 0 && row <= H - 1 && rad <= render_fraction * D)) continue;
             const double ey = erf(sqrt8 * (row - Y - 0.5) / D) - erf(sqrt8 * (row - Y + 0.5) / D);
             const float inc = (float)(sx * ey);
-            atomicAdd(&image[(size_t)row * W + col], inc);
+            atomicAdd(&image[(size_t)row * W + col], (double)inc);
             taps++;
         }
     }
@@ -274,7 +277,7 @@ __device__ __forceinline__ f3 sensor_hit(const Ray &ray, float a, float b, float
 }
 
 // intersect_sensor_02 (.cu:1383-1543): erf splat, x axis flipped.  Returns final position.
-__device__ __forceinline__ f3 sensor_diffraction(float *image, const Ray &ray, const camera_design_t &cam, int &taps) {
+__device__ __forceinline__ f3 sensor_diffraction(double *image, const Ray &ray, const camera_design_t &cam, int &taps) {
     const f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
     const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
     const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
@@ -288,7 +291,7 @@ __device__ __forceinline__ f3 sensor_diffraction(float *image, const Ray &ray, c
 
 // create_apparent_image (.cu:1545-1733): back-project to the object plane, scale by the
 // thin-lens magnification, splat with render_fraction 1.
-__device__ __forceinline__ f3 apparent_image(float *image, const Ray &ray, const camera_design_t &cam,
+__device__ __forceinline__ f3 apparent_image(double *image, const Ray &ray, const camera_design_t &cam,
                                              float z_object, float z_offset, const element_data_t &e, int &taps) {
     const f3 dir = -ray.dir;
     f3 hit = sensor_hit(ray, 0.0f, 0.0f, -1.0f, z_object, dir);
@@ -307,7 +310,7 @@ __device__ __forceinline__ f3 apparent_image(float *image, const Ray &ray, const
 }
 
 // intersect_sensor + 4-pixel area-weighted splat (.cu:1735-1895, :2199-2234)
-__device__ __forceinline__ f3 sensor_bilinear(float *image, const Ray &ray, const camera_design_t &cam, int &taps) {
+__device__ __forceinline__ f3 sensor_bilinear(double *image, const Ray &ray, const camera_design_t &cam, int &taps) {
     const f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
     const f3 dir = ray.dir;
     const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
@@ -333,7 +336,7 @@ __device__ __forceinline__ f3 sensor_bilinear(float *image, const Ray &ray, cons
         const long idx = (long)(ii[k] - 1) * W + jj[k] - 1;        // the reference's index (.cu:2228)
         if (idx < 0) continue;                                      // would write before the image
         const double inc = w[k] * ray.radiance * cos4;
-        atomicAdd(&image[idx], (float)inc);
+        atomicAdd(&image[idx], (double)(float)inc);
         taps++;
     }
     return hit;

@@ -9,7 +9,9 @@
 //          march_kernel<ALGO,INTERP>         ray generation + Mie lookup + world transform +
 //                                            Euler/RK4 march through the volume -> SoA ray state
 //          sensor_kernel<FROM_STATE>         (ray generation |) lens / aperture / apparent image
-//                                            + erf or 4-pixel splat with f32 atomics
+//                                            + erf or 4-pixel splat, f64 atomics into a private
+//                                            accumulator
+//          finalize_image_kernel             image = (float)(image + accumulator)
 //
 // The product has no CPU compute path: if HIP reports an error the call fails loudly
 // (message on stderr, non-zero return / untouched image).
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void march_kernel(SceneDev sc, VolumeDev vol, 
 // (no density gradients) generates the ray in place, so that path is one fused kernel.
 template <bool FROM_STATE>
 __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
-                                                     float *image, DumpDev dump, unsigned long long *counters) {
+                                                     double *image, DumpDev dump, unsigned long long *counters) {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     int taps = 0;
     unsigned on_sensor = 0;
@@ -307,6 +309,14 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
     wave_add(&counters[CNT_ON_SENSOR], (unsigned long long)on_sensor);
 }
 
+// image_array is read-modify-write (parallel_ray_tracing.cu:3309,3675): fold the f64 accumulator of
+// this call into the caller's f32 image, one rounding per pixel.
+__global__ __launch_bounds__(256) void finalize_image_kernel(float *__restrict__ image, const double *__restrict__ acc,
+                                                             size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) image[i] = (float)((double)image[i] + acc[i]);
+}
+
 // =============================================================================================
 // host: handles
 // =============================================================================================
@@ -323,6 +333,7 @@ struct photon_scene {
     RayStateDev ws{};                   // march -> sensor state, grown on demand
     size_t ws_rays = 0;
     unsigned long long *d_counters = nullptr;
+    double *d_acc = nullptr;            // f64 sensor accumulator, W*H
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -575,6 +586,7 @@ void photon_scene_free(photon_scene_t *s) {
     if (s->ws.px) (void)hipFree(s->ws.px);
     if (s->ws.radiance) (void)hipFree(s->ws.radiance);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_acc) (void)hipFree(s->d_acc);
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -644,6 +656,8 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
     }
     hipError_t e = hipMalloc((void **)&s->d_counters, CNT_N * sizeof(unsigned long long));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    e = hipMalloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
+    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     for (auto &ev : s->ev) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { fprintf(stderr, "photon: hipEventCreate failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
@@ -671,9 +685,23 @@ static int ensure_workspace(photon_scene *s, size_t rays) {
     return 0;
 }
 
+static int begin_accumulate(photon_scene *s, hipStream_t stream) {
+    const size_t npix = (size_t)s->dev.cam.x_pixel_number * s->dev.cam.y_pixel_number;
+    PH_CHECK(hipMemsetAsync(s->d_acc, 0, npix * sizeof(double), stream));
+    return 0;
+}
+static int end_accumulate(photon_scene *s, float *d_image, hipStream_t stream) {
+    const size_t npix = (size_t)s->dev.cam.x_pixel_number * s->dev.cam.y_pixel_number;
+    hipLaunchKernelGGL(finalize_image_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, d_image,
+                       s->d_acc, npix);
+    PH_CHECK(hipGetLastError());
+    return 0;
+}
+
 // One launch group over sources [src_begin, src_end): n rays = sources * rays_per_source.
 static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
-                        long long src_end, float *d_image, DumpDev dump, hipStream_t stream, bool timed) {
+                        long long src_end, DumpDev dump, hipStream_t stream, bool timed) {
+    double *d_image = s->d_acc;
     const unsigned long long n64 = (unsigned long long)(src_end - src_begin) * (unsigned)s->dev.rays_per_source;
     if (n64 == 0) return 0;
     if (n64 > kMaxRaysPerLaunch) return 1;
@@ -720,9 +748,10 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
     }
     float march_ms = 0.f;
     const DumpDev no_dump{nullptr, nullptr, 0};
+    { const int rc = begin_accumulate(scene, stream); if (rc) return rc; }
     for (long long b = src_begin; b < src_end; b += max_sources) {
         const long long e = std::min<long long>(src_end, b + max_sources);
-        const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, d_image, no_dump, stream, stats != nullptr);
+        const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, no_dump, stream, stats != nullptr);
         if (rc) return rc;
         if (stats && vol) {
             PH_CHECK(hipEventSynchronize(scene->ev[2]));
@@ -731,6 +760,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
             march_ms += ms;
         }
     }
+    { const int rc = end_accumulate(scene, d_image, stream); if (rc) return rc; }
     if (stats) {
         PH_CHECK(hipEventRecord(scene->ev[3], stream));
         PH_CHECK(hipEventSynchronize(scene->ev[3]));
@@ -878,18 +908,20 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
         PH_VOID(hipMalloc((void **)&d_fdir, nsave * sizeof(float)));
         std::vector<float> host(nsave);
         const long long kmax = (num_particles + chunk - 1) / chunk;
+        rc = begin_accumulate(scene, nullptr);
         for (long long k = 0; k < kmax && rc == 0; k++) {
             PH_VOID(hipMemset(d_fpos, 0xFF, nsave * sizeof(float)));    // all-ones = NaN (.cu:3527-3533)
             PH_VOID(hipMemset(d_fdir, 0xFF, nsave * sizeof(float)));
             const DumpDev dump{d_fpos, d_fdir, num_lightrays_save};
             rc = launch_chunk(scene, vol, ray_tracing_algorithm, k * chunk, std::min(num_particles, (k + 1) * chunk),
-                              d_image, dump, nullptr, false);
+                              dump, nullptr, false);
             if (rc) break;
             PH_VOID(hipMemcpy(host.data(), d_fpos, nsave * sizeof(float), hipMemcpyDeviceToHost));
             write_dump(lightray_position_save_path, "pos_", (int)k, host);
             PH_VOID(hipMemcpy(host.data(), d_fdir, nsave * sizeof(float), hipMemcpyDeviceToHost));
             write_dump(lightray_direction_save_path, "dir_", (int)k, host);
         }
+        if (rc == 0) rc = end_accumulate(scene, d_image, nullptr);
     } else {
         rc = photon_trace(scene, vol, ray_tracing_algorithm, 0, num_particles, d_image, nullptr, nullptr);
     }
