@@ -12,7 +12,7 @@
 namespace photon {
 
 struct f3 { float x, y, z; };
-struct f4 { float x, y, z, w; };
+struct alignas(16) f4 { float x, y, z, w; };     // 16-byte aligned: one dwordx4 / ds_read_b128 per texel
 
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }

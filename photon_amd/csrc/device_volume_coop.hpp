@@ -1,0 +1,278 @@
+// device_volume_coop.hpp - wave-cooperative, LDS-staged volume samplers and the RK4 march built
+// on them (the hot loop of the library).
+//
+// Why: rays are laid out source-major, so the 64 lanes of a wave start at one light-field source
+// and stay within a fraction of a texel of each other through the volume (ray_cone_pitch_ratio is
+// 1e-4 for BOS; a full PIV cone spreads over a few texels).  Nearly every sample of a wave needs the
+// SAME 4x4x4 (tricubic) / 2x2x2 (trilinear) texel block, only the weights differ per lane.  A
+// per-lane gather issues 64 x 64 16-byte loads for it and is bound by the vector-memory address
+// path (measured: 273 ms for 1e7 rays through 256^3).  Here instead:
+//
+//   * the march is WAVE-SYNCHRONOUS: all 64 lanes stay in the loop until the last ray of the wave
+//     has left the volume (finished lanes are predicated off), so every lane is available for
+//     cooperative work at each sample;
+//   * lanes are grouped by base texel (a short waterfall over the distinct blocks of the wave);
+//     for each group the whole wave fetches the block with ONE load instruction -- lane l loads
+//     texel (l&3, (l>>2)&3, l>>4) of the block, clamp-to-edge applied per texel, 64 lanes x 16 B --
+//     and parks it in the wave's 1 KiB LDS tile;
+//   * the lanes of the group then run the separable 64-tap fmaf chain reading the texels back
+//     with broadcast ds_read_b128 (all lanes read the same address: conflict-free).
+//   * waves that are not coherent (more than kCoopGroups distinct blocks) finish the remaining
+//     lanes with the per-lane gather.
+//
+// Every path evaluates the same fmaf chain in the same order: results are bit-identical to the
+// per-lane samplers in device_volume.hpp and to the CPU oracle.
+#pragma once
+#include "device_volume.hpp"
+
+namespace photon {
+
+constexpr int kCoopGroups = 4;          // distinct texel blocks served cooperatively per sample
+
+// 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c).
+// Texels are handled as 4-wide vectors (one ds_read_b128 each); the per-component operation
+// sequence is exactly the scalar fmaf chain of tex3d_cubic().
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f splat4(float s) { return v4f{s, s, s, s}; }
+__device__ __forceinline__ v4f fma4(float w, v4f t, v4f acc) { return __builtin_elementwise_fma(splat4(w), t, acc); }
+
+// sum over one z-slab: 16 texels, x innermost
+__device__ __forceinline__ v4f cubic_slab_lds(const v4f *q, const float (&wx)[4], const float (&wy)[4]) {
+    v4f plane = splat4(0.f);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const v4f *row = q + b * 4;
+        v4f r = splat4(wx[0]) * row[0];
+        r = fma4(wx[1], row[1], r);
+        r = fma4(wx[2], row[2], r);
+        r = fma4(wx[3], row[3], r);
+        plane = (b == 0) ? splat4(wy[0]) * r : fma4(wy[b], r, plane);
+    }
+    return plane;
+}
+
+__device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4], const float (&wy)[4],
+                                             const float (&wz)[4]) {
+    const v4f *q = reinterpret_cast<const v4f *>(blk);
+    v4f acc = splat4(wz[0]) * cubic_slab_lds(q, wx, wy);
+    // A compiler memory barrier between z-slabs: without it the scheduler hoists all 64 texel
+    // reads to the top (256 VGPRs in flight, one wave per SIMD).  One slab = 16 reads = 64 VGPRs
+    // covers the LDS latency and leaves room for more waves per SIMD.
+#pragma unroll
+    for (int c = 1; c < 4; c++) {
+        asm volatile("" ::: "memory");
+        acc = fma4(wz[c], cubic_slab_lds(q + c * 16, wx, wy), acc);
+    }
+    return f4{acc.x, acc.y, acc.z, acc.w};
+}
+
+// Must be called by ALL 64 lanes of the wave (wave-uniform control flow); `need` says whether this
+// lane wants a sample.  blk = this wave's 64-texel LDS tile.
+__device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
+                                               float x, float y, float z) {
+    const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
+    const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
+    float wx[4], wy[4], wz[4];
+    bspline_weights(xg - fi, wx[0], wx[1], wx[2], wx[3]);
+    bspline_weights(yg - fj, wy[0], wy[1], wy[2], wy[3]);
+    bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
+    const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
+    const int lane = threadIdx.x & 63;
+    const int ta = lane & 3, tb = (lane >> 2) & 3, tc = lane >> 4;
+    const size_t W = v.nx, WH = (size_t)v.nx * v.ny;
+    f4 acc = f4{0, 0, 0, 0};
+    bool done = !need;
+#pragma unroll 1
+    for (int g = 0; g < kCoopGroups; g++) {
+        const unsigned long long todo = __ballot(!done);
+        if (todo == 0) break;                                   // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
+                  ck = __builtin_amdgcn_readlane(bk, leader);
+        // one coalesced-ish load instruction for the whole block: 16 rows of 64 contiguous bytes
+        const int tx = clampi(ci - 1 + ta, 0, v.nx - 1), ty = clampi(cj - 1 + tb, 0, v.ny - 1),
+                  tz = clampi(ck - 1 + tc, 0, v.nz - 1);
+        const f4 t = ldtexel(tex + tz * WH + ty * W + tx);
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+        __builtin_amdgcn_wave_barrier();
+        if (!done && bi == ci && bj == cj && bk == ck) {
+            acc = cubic_taps_lds(blk, wx, wy, wz);
+            done = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!done) acc = cubic_taps_gather(tex, v.nx, v.ny, v.nz, bi, bj, bk, wx, wy, wz);     // incoherent wave
+    return acc;
+}
+
+__device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
+                                                float x, float y, float z) {
+    const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
+    const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
+    const float a = xb - fi, b = yb - fj, c = zb - fk;
+    const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
+    const int lane = threadIdx.x & 63;
+    const int ta = lane & 1, tb = (lane >> 1) & 1, tc = (lane >> 2) & 1;
+    const size_t W = v.nx, WH = (size_t)v.nx * v.ny;
+    f4 acc = f4{0, 0, 0, 0};
+    bool done = !need;
+#pragma unroll 1
+    for (int g = 0; g < kCoopGroups; g++) {
+        const unsigned long long todo = __ballot(!done);
+        if (todo == 0) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
+                  ck = __builtin_amdgcn_readlane(bk, leader);
+        const int tx = clampi(ci + ta, 0, v.nx - 1), ty = clampi(cj + tb, 0, v.ny - 1),
+                  tz = clampi(ck + tc, 0, v.nz - 1);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 8) {
+            const f4 t = ldtexel(tex + tz * WH + ty * W + tx);
+            *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!done && bi == ci && bj == cj && bk == ck) {
+            // blk[tc*4 + tb*2 + ta]; same lerp tree as tex3d_linear
+            const f4 c00 = lerp4(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4(ldtexel(blk + 2), ldtexel(blk + 3), a);
+            const f4 c01 = lerp4(ldtexel(blk + 4), ldtexel(blk + 5), a), c11 = lerp4(ldtexel(blk + 6), ldtexel(blk + 7), a);
+            const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
+            acc = lerp4(c0, c1, c);
+            done = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!done) acc = linear_taps<true>(tex, v.nx, v.ny, v.nz, bi, bj, bk, a, b, c);
+    return acc;
+}
+
+// One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
+template <int INTERP>
+__device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need, f3 lookup,
+                                          const f4 &val_prev, MarchCount &mc) {
+    f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z)
+                         : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z);
+    if (need) mc.samples++;
+    if (INTERP == 1) {
+        const float ambient = 1.000277;
+        const bool low = need && val.w < v.data_min;
+        const bool repair = low && val_prev.w == 0;
+        if (__ballot(repair) != 0) {                            // wave-uniform, rare
+            const f4 t = tex3d_linear_coop(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1);
+            if (repair) { mc.samples++; val = f4{t.x, t.y, t.z, ambient - 1}; }
+        }
+        if (low && !repair) val = val_prev;
+    }
+    return val;
+}
+
+// Wave-synchronous RK4 (reference: trace_rays_through_density_gradients.h:952-1291).  All 64
+// lanes call it; `active` = this lane carries a ray that is inside (or entering) the volume.  One
+// trip of the loop is one RK4 iteration: Sharma's three samples A, B, C in straight-line code with
+// a cooperative sampler call each.  A lane whose ray leaves the box is predicated off (the
+// reference's `break`); a lane that has to step forward without sampling (the reference's
+// `continue`) sits out the rest of the trip and retries on the next one.  The per-ray operation
+// order is that of rk4<> in device_volume.hpp.
+template <int INTERP>
+__device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
+                                         const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc) {
+    int loop_ctr = 0, spins = 0;
+    f4 val_prev = f4{0, 0, 0, 0};
+    while (__ballot(active) != 0) {                             // wave-uniform loop
+        // ---------------- sample A at R_n ----------------
+        bool need = false;
+        f3 lookup = mk3(0, 0, 0);
+        if (active) {
+            if (loop_ctr > kLoopMax) {
+                active = false;
+            } else {
+                lookup = lookup_index(rpos, v, scale);
+                if (!inside_box(rpos, v, lookup) && loop_ctr != 0) {
+                    active = false;                             // left the volume: done
+                } else if (!can_access(v, lookup)) {            // .h:1043-1049
+                    rpos = rpos + v.step_size / (1 + v.data_min) * rdir;
+                    if (++spins > kSpinMax) active = false;
+                } else {
+                    need = true;
+                }
+            }
+        }
+        f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        bool go = false;                                        // lane continues to samples B and C
+        f3 R_n = rpos, T_n = rdir, A = mk3(0, 0, 0), B = mk3(0, 0, 0), spos = rpos;
+        float delta_t = 0.f, current_n = 1.f;
+        if (need) {
+            if (INTERP == 2 && val.w < v.data_min) {            // .h:1220-1227
+                rpos = rpos + v.step_size / (1 + v.data_min) * rdir;
+                if (++spins > kSpinMax) active = false;
+            } else {
+                loop_ctr += 1;
+                val.w += 1;
+                current_n = val.w;
+                delta_t = v.step_size / val.w;
+                T_n = val.w * rdir;
+                A = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+                spos = R_n + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;       // .h:1088
+                if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
+                go = true;
+            }
+        }
+        // ---------------- sample B ----------------
+        need = false;
+        if (go) {
+            lookup = lookup_index(spos, v, scale);
+            if (!inside_box(spos, v, lookup)) { active = false; go = false; }       // .h:1094-1101
+            else need = true;
+        }
+        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        if (need) {
+            val.w += 1;
+            B = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+            spos = R_n + delta_t * T_n + (0.5f * delta_t) * B;                      // .h:1131
+            if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
+        }
+        // ---------------- sample C ----------------
+        need = false;
+        if (go) {
+            lookup = lookup_index(spos, v, scale);
+            if (!inside_box(spos, v, lookup)) { active = false; go = false; }       // .h:1135-1141
+            else need = true;
+        }
+        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        if (need) {
+            val.w += 1;
+            const f3 C = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+            R_n = R_n + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));        // .h:1169
+            T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);                      // .h:1170
+            rpos = R_n;
+            rdir = normalize(T_n / (INTERP == 1 ? current_n : val.w));              // .h:1178 / 1276
+            if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
+            mc.iterations++;
+        }
+    }
+}
+
+// trace_rays_through_density_gradients (.h:1455-1544), wave-synchronous.  has_ray = this lane
+// carries a ray at all (tail lanes of the last workgroup do not).
+template <int ALGO, int INTERP>
+__device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &dir_io, const VolumeDev &v,
+                                                  const f4 *__restrict__ tex, f4 *blk, MarchCount &mc) {
+    const f3 mn = v.min_bound, mx = v.max_bound;
+    const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
+    bool active = has_ray;
+    if (has_ray) {
+        f3 pos = pos_io;
+        const f3 dir = dir_io;
+        if (pos.x <= mn.x || pos.y <= mn.y || pos.z <= mn.z || pos.x >= mx.x || pos.y >= mx.y || pos.z >= mx.z) {
+            if (!intersect_with_volume(pos, dir, mn, mx)) active = false;      // miss: ray unchanged
+        }
+        if (active) pos_io = pos;
+    }
+    if (ALGO == 1) {
+        if (active) euler<INTERP>(pos_io, dir_io, v, scale, mc);
+    } else {
+        rk4_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc);
+    }
+}
+
+}  // namespace photon

@@ -39,6 +39,7 @@
 #include "device_optics.hpp"
 #include "device_vec.hpp"
 #include "device_volume.hpp"
+#include "device_volume_coop.hpp"
 
 using namespace photon;
 
@@ -206,16 +207,24 @@ __global__ __launch_bounds__(256) void sample_kernel(VolumeDev v, int n, const f
 }
 
 template <int ALGO, int INTERP>
-__global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, int n, float *pos, float *dir, int *steps) {
+__global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *__restrict__ tex, int n,
+                                                         float *__restrict__ pos, float *__restrict__ dir,
+                                                         int *__restrict__ steps) {
+    __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    f3 p = mk3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
-    f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    const bool has_ray = i < n;
+    f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
+    if (has_ray) {
+        p = mk3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    }
     MarchCount mc{0, 0};
-    trace_volume<ALGO, INTERP>(p, d, v, mc);
-    pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
-    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
-    if (steps) steps[i] = mc.iterations;
+    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc);
+    if (has_ray) {
+        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+        dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+        if (steps) steps[i] = mc.iterations;
+    }
 }
 
 // =============================================================================================
@@ -226,27 +235,34 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, int n, flo
 // it, move it back (parallel_ray_tracing.cu:2004-2131), store the state SoA.  One lane per ray,
 // rays source-major so the 64 lanes of a wave start from (almost) the same point.
 template <int ALGO, int INTERP>
-__global__ __launch_bounds__(256) void march_kernel(SceneDev sc, VolumeDev vol, long long src_begin, unsigned n_rays,
-                                                    RayStateDev st, unsigned long long *counters) {
+__global__ __launch_bounds__(256) void march_kernel(SceneDev sc, VolumeDev vol, const f4 *__restrict__ tex,
+                                                    long long src_begin, unsigned n_rays, RayStateDev st,
+                                                    unsigned long long *__restrict__ counters) {
+    __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
+    const bool has_ray = r < n_rays;
     MarchCount mc{0, 0};
-    if (r < n_rays) {
+    f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
+    double radiance = 0.0;
+    if (has_ray) {
         const unsigned rps = (unsigned)sc.rays_per_source;
         const int source = (int)(src_begin + r / rps);
         const int local_ray = (int)(r % rps);
-        Ray ray = generate_ray(sc, source, local_ray);
-        f3 p = ray.pos, d = ray.dir;
+        const Ray ray = generate_ray(sc, source, local_ray);
+        p = ray.pos; d = ray.dir; radiance = ray.radiance;
         p.z = (float)(p.z - (sc.z_offset + 750e3));                     // .cu:2045
         p = matvec(sc.cam.inverse_rotation_matrix, p);                  // camera -> world
         d = matvec(sc.cam.inverse_rotation_matrix, d);
-        trace_volume<ALGO, INTERP>(p, d, vol, mc);
+    }
+    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc);   // all 64 lanes
+    if (has_ray) {
         p = matvec(sc.cam.rotation_matrix, p);                          // world -> camera
         d = normalize(matvec(sc.cam.rotation_matrix, d));
         p.z = (float)(p.z + (sc.z_offset + 750e3));                     // .cu:2119
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
-        st.radiance[r] = ray.radiance;
+        st.radiance[r] = radiance;
     }
     wave_add(&counters[CNT_ITER], (unsigned long long)mc.iterations);
     wave_add(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
@@ -568,10 +584,11 @@ int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorit
     PH_CHECK(hipMemcpy(d_d, dir, b3, hipMemcpyHostToDevice));
     const dim3 grid((n + 255) / 256), block(256);
     const int interp = vol->dev.interpolation;
-    if (ray_tracing_algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_rays_kernel<1, 1>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
-    else if (ray_tracing_algorithm == 1) hipLaunchKernelGGL((march_rays_kernel<1, 2>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
-    else if (interp == 1) hipLaunchKernelGGL((march_rays_kernel<2, 1>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
-    else hipLaunchKernelGGL((march_rays_kernel<2, 2>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
+    if (ray_tracing_algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_rays_kernel<1, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
+    else if (ray_tracing_algorithm == 1) hipLaunchKernelGGL((march_rays_kernel<1, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
+    else if (interp == 1) hipLaunchKernelGGL((march_rays_kernel<2, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
+    else hipLaunchKernelGGL((march_rays_kernel<2, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
     PH_CHECK(hipGetLastError());
     PH_CHECK(hipMemcpy(pos, d_p, b3, hipMemcpyDeviceToHost));
     PH_CHECK(hipMemcpy(dir, d_d, b3, hipMemcpyDeviceToHost));
@@ -712,10 +729,11 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         if (rc) return rc;
         if (timed) PH_CHECK(hipEventRecord(s->ev[1], stream));
         const int interp = vol->dev.interpolation;
-        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
-        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
-        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
-        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, s->dev, vol->dev, src_begin, n, s->ws, s->d_counters);
+        const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
+        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
+        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
+        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
+        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
         PH_CHECK(hipGetLastError());
         if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
         hipLaunchKernelGGL((sensor_kernel<true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);

@@ -1,0 +1,51 @@
+"""include/photon_det_math.h (host build, via the oracle library) against numpy's libm.
+
+These functions replace atanf/tanf/cos/sin/acosf on the ray path so that oracle and HIP kernels
+produce identical bits; here we pin their ACCURACY independently of both."""
+import numpy as np
+import pytest
+
+SIN, COS, TAN, ATAN, ACOS, ATANF, TANF, ACOSF, COSF = 0, 1, 2, 3, 4, 10, 11, 12, 13
+
+
+def ulps(y, ref):
+    return np.abs(y - ref) / np.spacing(np.abs(ref))
+
+
+def test_double_functions_within_4_ulp(oracle):
+    rng = np.random.default_rng(0)
+    t = rng.uniform(0.0, 2 * np.pi, 200_000)
+    for fn, ref in ((SIN, np.sin), (COS, np.cos)):
+        y = oracle.det_eval(fn, t)
+        r = ref(t.astype(np.longdouble)).astype(np.float64)
+        assert np.abs(y - r).max() <= 2.3e-16            # absolute: what the callers need
+    x = rng.uniform(-1.5, 1.5, 200_000)
+    assert ulps(oracle.det_eval(TAN, x), np.tan(x.astype(np.longdouble)).astype(np.float64)).max() <= 4
+    x = np.concatenate([rng.uniform(-3, 3, 200_000), 10 * rng.standard_cauchy(100_000)])
+    assert ulps(oracle.det_eval(ATAN, x), np.arctan(x.astype(np.longdouble)).astype(np.float64)).max() <= 4
+    x = rng.uniform(-1, 1, 200_000)
+    assert ulps(oracle.det_eval(ACOS, x), np.arccos(x.astype(np.longdouble)).astype(np.float64)).max() <= 5
+
+
+@pytest.mark.parametrize("fn,ref,lo,hi", [(ATANF, np.arctan, -0.3, 0.3), (TANF, np.tan, -0.3, 0.3),
+                                          (ATANF, np.arctan, -50.0, 50.0), (TANF, np.tan, -1.5, 1.5),
+                                          (ACOSF, np.arccos, -1.0, 1.0), (COSF, np.cos, 0.0, 1.5)])
+def test_float_functions_are_correctly_rounded(oracle, fn, ref, lo, hi):
+    """f32 results = correctly rounded value (<= 1 ulp allowed, and at most 1e-5 of cases off)."""
+    rng = np.random.default_rng(fn)
+    x = rng.uniform(lo, hi, 300_000).astype(np.float32)
+    y = oracle.det_eval(fn, x.astype(np.float64)).astype(np.float32)
+    cr = ref(x.astype(np.longdouble)).astype(np.float32)
+    off = y != cr
+    assert off.mean() <= 1e-5
+    assert (np.abs(y.astype(np.float64) - cr) <= np.spacing(np.abs(cr))).all()
+
+
+def test_special_values(oracle):
+    a = oracle.det_eval(ACOS, [1.0, 0.0])
+    assert a[0] == 0.0 and a[1] == pytest.approx(np.pi / 2, abs=4e-16)
+    assert oracle.det_eval(ACOS, [-1.0])[0] == pytest.approx(np.pi, abs=1e-15)
+    assert np.isnan(oracle.det_eval(ACOS, [1.5, -1.0000001, np.nan])).all()
+    a = oracle.det_eval(ATAN, [np.inf, -np.inf, 0.0, np.nan])
+    assert a[0] == pytest.approx(np.pi / 2) and a[1] == pytest.approx(-np.pi / 2) and a[2] == 0.0 and np.isnan(a[3])
+    assert oracle.det_eval(SIN, [0.0])[0] == 0.0 and oracle.det_eval(COS, [0.0])[0] == 1.0

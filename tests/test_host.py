@@ -1,0 +1,79 @@
+"""Host-side logic without a GPU: marshalling mirror, sensor post-processing, scene helpers,
+NRRD round trip, source sharding."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from photon_amd import scenes
+from photon_amd.ray_tracing import postprocess_image, single_lens_camera
+from photon_amd.sharding import shard_range
+
+
+@pytest.mark.parametrize("case", ["piv", "bos_im1", "bos_im2"])
+def test_postprocess_matches_reference(case):
+    """uint16 image the reference's post-processing (perform_ray_tracing_03.py:2190-2247) made of a
+    synthetic raw image == ours, pixel for pixel."""
+    a = np.load(os.path.join(GOLDEN, f"postprocess_{case}.npz"))
+    with open(os.path.join(GOLDEN, f"abi_{case}.json")) as f:
+        pp = json.load(f)["postprocess"]
+    shape = tuple(int(v) for v in a["shape"])
+    raw = np.zeros(shape[0] * shape[1], np.float32)
+    raw[a["raw_index"]] = a["raw_value"]
+    out = postprocess_image(raw.reshape(shape), pp["pixel_gain"], int(pp["pixel_bit_depth"]),
+                            pp["intensity_rescaling"], pp["image_noise"])
+    ref = np.zeros(shape[0] * shape[1], np.uint16)
+    ref[a["out_u16_index"]] = a["out_u16_value"]
+    assert out.dtype == np.uint16 and np.array_equal(out.reshape(-1), ref)
+
+
+def test_single_lens_camera_matches_reference_numbers():
+    """Values the reference derives for its sample lens (captured via its marshalling code)."""
+    g = single_lens_camera(105000.0, 8.0, 700000.0, 100000.0)
+    with open(os.path.join(GOLDEN, "abi_bos_im1.json")) as f:
+        j = json.load(f)
+    a = np.load(os.path.join(GOLDEN, "abi_bos_im1.npz"))
+    assert g["lens_pitch"] == j["scalars"]["lens_pitch"]
+    assert g["image_distance"] == pytest.approx(j["scalars"]["image_distance"], rel=1e-15)
+    eg = j["elements"][0]["element_geometry"]
+    assert g["element"]["element_geometry"]["vertex_distance"] == pytest.approx(eg["vertex_distance"], rel=1e-14)
+    assert g["element"]["element_properties"]["refractive_index"] == pytest.approx(
+        j["elements"][0]["element_properties"]["refractive_index"], rel=1e-14)
+    assert np.allclose(g["element_center"], a["element_center"], rtol=1e-14)
+    assert np.allclose(g["element_plane_parameters"], a["element_plane_parameters"], rtol=1e-14)
+    assert np.float32(g["z_offset"]) == np.float32(j["source"]["z_offset"])
+    assert np.float32(g["z_object"]) == a["src_z"][0]      # BOS sources sit on the object plane
+
+
+def test_nrrd_round_trip(tmp_path):
+    rho, sp, org = scenes.bos_volume(16)
+    p = scenes.write_nrrd(str(tmp_path / "v.nrrd"), rho, sp, org)
+    r2, sp2, org2 = scenes.read_nrrd(p)
+    assert np.array_equal(rho, r2) and list(sp2) == list(sp) and list(org2) == list(org)
+    # the reference's own sample file parses too
+    r, sp, org = scenes.read_nrrd(os.path.join(GOLDEN, "sample-density.nrrd"))
+    assert r.shape == (64, 64, 64) and sp == [519.5459, 519.5459, 519.5]
+    assert org == [-16365.714, -16365.714, 733634.3]
+
+
+def test_scene_sizes():
+    c3 = scenes.bos_scene()
+    assert c3.num_sources == 20000 and c3.num_rays == 10_000_000 and c3.camera["implement_diffraction"]
+    c2 = scenes.piv_scene()
+    assert c2.num_rays == 1_000_000 and c2.scattering_irradiance.shape == (255, 27)
+    c0 = scenes.config("C0")
+    assert c0.num_rays == 10_000 and c0.scattering_type == "diffuse"
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 20000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)

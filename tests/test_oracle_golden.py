@@ -1,0 +1,186 @@
+"""Pinning the CPU oracle.
+
+The reference ships no tests or golden vectors, and its GPU path cannot be built here.  The oracle
+is pinned by (a) vectors generated in this container by the reference's own Python
+(tests/golden/make_golden.py) and (b) known answers implied by the reference's formulas."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_fixture_call
+from photon_amd import scenes
+from photon_amd.ray_tracing import single_lens_camera
+
+
+# ---- (a) vectors from the reference's Python -----------------------------------------------------
+def test_glibc_rand_table_known_answer(oracle):
+    """srand(10) sequence, SURVEY.md section 8a row a2 (glibc 2.35)."""
+    r1, r2 = oracle.rand_table(3)
+    assert np.allclose(r1, [0.56581074, 0.505768061, 0.816686273], rtol=0, atol=1e-8)
+    assert np.allclose(r2, [0.610929906, 0.179646879, 0.18347165], rtol=0, atol=1e-8)
+
+
+@pytest.fixture(scope="module")
+def lens():
+    return np.load(os.path.join(GOLDEN, "lens_f64.npz"))
+
+
+@pytest.mark.parametrize("tag", ["front", "back"])
+def test_ray_sphere_intersection_vs_reference_numpy(oracle, lens, tag):
+    """f32 device arithmetic (with its catastrophic cancellation, .cu:271-276) against the
+    reference's float64 ancestor (perform_ray_tracing_03.py:472): the intersection lies on the
+    same ray; along-ray error is bounded by the f32 cancellation (< 1 micron here), lateral error
+    is that times the ray slope."""
+    din = lens[f"rsi_{tag}_in"]
+    c = lens[f"rsi_{tag}_c"]
+    ref = lens[f"rsi_{tag}_out"]
+    out = oracle.ray_sphere_intersection(c[:3], c[3], din[:, 3:6], din[:, 0:3], tag[0])
+    assert not np.isnan(out).any() and not np.isnan(ref).any()
+    err = np.abs(out.astype(np.float64) - ref)
+    assert err[:, 2].max() < 1.5                      # microns along z, out of ~7e5 travelled
+    assert err[:, :2].max() < 0.15                    # lateral
+    # and the hit really is on the sphere to f32 accuracy
+    r = np.linalg.norm(out.astype(np.float64) - c[:3], axis=1)
+    assert np.abs(r - abs(c[3])).max() < 1.0
+
+
+def test_axis_distance_vs_reference_numpy(oracle, lens):
+    z_lens = 123598.87980659823
+    out = oracle.axis_distance(lens["axis_in"], [0, 0, z_lens], [0, 0, 1, -z_lens])
+    assert np.allclose(out, lens["axis_out"], rtol=2e-6)
+
+
+def test_thick_lens_element_vs_reference_numpy(oracle, lens):
+    """Whole 'l' element (perform_ray_tracing_03.py:671 vs parallel_ray_tracing.cu:507-864)."""
+    g = single_lens_camera(105000.0, 8.0, 700000.0, 100000.0)
+    pin = lens["lens_in"]
+    p, d, rad = oracle.single_element(g["element"], g["element_center"][0], g["element_plane_parameters"][0],
+                                      pin[:, 0:3], pin[:, 3:6], 0.532, np.ones(len(pin)))
+    ref = lens["lens_out"]
+    dead_ref, dead = np.isnan(ref[:, 0]), np.isnan(p[:, 0])
+    assert 0.3 < dead_ref.mean() < 0.7                                   # ~half the rays miss the aperture
+    assert (dead_ref != dead).mean() < 2e-3                              # edge rays may flip
+    ok = ~dead_ref & ~dead
+    assert np.abs(p[ok].astype(np.float64) - ref[ok, 0:3]).max() < 1.5   # microns
+    assert np.abs(d[ok].astype(np.float64) - ref[ok, 3:6]).max() < 5e-6  # direction cosines
+    assert np.allclose(rad[ok], lens["lens_out_radiance"][ok])
+
+
+def test_sample_bos_volume_is_missed_by_every_ray(oracle):
+    """with the shipped sample geometry the slab test fails for every ray, so
+    the 'distorted' image only differs from the reference image by the f32 world-transform round
+    trip."""
+    call = load_fixture_call("bos_im2")
+    assert call.simulate_density_gradients and os.path.exists(call.density_grad_filename)
+    img2, st = oracle.render(call)
+    assert st.rk_iterations == 0 and st.volume_samples == 0 and st.rays_on_sensor > 0
+    img1, _ = oracle.render(load_fixture_call("bos_im1"))
+    rel = np.linalg.norm(img2.astype(np.float64) - img1) / np.linalg.norm(img1)
+    assert 0 < rel < 2e-3        # ~2e-4: the f32 noise floor that motivates include/photon_det_math.h
+
+
+def test_sample_nrrd_header_and_bounds(oracle):
+    v = oracle.volume_load_nrrd(os.path.join(GOLDEN, "sample-density.nrrd"))
+    i = v.info()
+    assert (i.nx, i.ny, i.nz) == (64, 64, 64)
+    assert i.min_bound[2] == np.float32(733634.3 - 750e3)               # the -750e3 shift (.h:1704)
+    assert i.max_bound[0] == np.float32(-16365.714 + 63 * 519.5459)
+    assert i.step_size == np.float32(519.5)
+    tex = v.download()
+    n1 = tex[..., 3]
+    assert np.float32(0.225e-3) * np.float32(6.19) * 0.99 < n1.min() == i.data_min < n1.max() < 0.225e-3 * 6.77
+    v.free()
+
+
+# ---- (b) known answers implied by the formulas ---------------------------------------------------
+def _linear_density(n, spacing, grad_x):
+    x = np.arange(n) * spacing
+    return np.broadcast_to((1.225 + grad_x * x)[None, None, :], (n, n, n)).astype(np.float32)
+
+
+@pytest.mark.parametrize("interp", [1, 2])
+@pytest.mark.parametrize("algorithm", [1, 2])
+def test_constant_gradient_deflection(oracle, interp, algorithm):
+    """A ray along z through a medium with constant dn/dx over length L is deflected by
+    eps = (dn/dx) L / n0 (reference: python_codes/nrrd_functions.py:60-82, check_density_gradients
+    .cu:2965-3071)."""
+    n, h = 64, 100.0
+    drho = 2.0e-4                                        # density per micron
+    rho = _linear_density(n, h, drho)
+    v = oracle.volume_from_density(rho, (h, h, h), (-3150.0, -3150.0, 750e3), interp)
+    dn_dx = 0.225e-3 * drho
+    tex = v.download()
+    assert np.allclose(tex[..., 0], dn_dx, rtol=2e-3) and np.allclose(tex[..., 1:3], 0, atol=1e-12)
+    pos = np.array([[0.0, 0.0, 6300.0 + 500.0]], np.float32).repeat(8, 0)
+    pos[:, 0] = np.linspace(-1000, 1000, 8)
+    d = np.array([[0.0, 0.0, -1.0]], np.float32).repeat(8, 0)
+    p, dd, steps = v.trace_rays(pos, d, algorithm)
+    L = steps * h                                        # path marched inside the box
+    eps = dd[:, 0] / -dd[:, 2]
+    n0 = 1.0 + 0.225e-3 * 1.225
+    assert (steps >= n - 3).all()
+    assert np.allclose(eps, dn_dx * L / n0, rtol=0.03)
+    assert np.abs(dd[:, 1]).max() < 1e-9
+    v.free()
+
+
+def test_tricubic_interpolates_at_the_knots(oracle):
+    """prefilter o tricubic sampled at texel centres returns the samples
+    (CubicInterpolationCUDA/examples/cudaAccuracyTest/cudaAccuracyTest_kernel.cu:79-100)."""
+    rng = np.random.default_rng(2)
+    n = 24
+    rho = (1.0 + 0.5 * rng.random((n, n, n))).astype(np.float32)
+    v = oracle.volume_from_density(rho, (100.0, 100.0, 100.0), (0.0, 0.0, 750e3), 2)
+    data = v.download(False)
+    k, j, i = np.meshgrid(*(np.arange(6, n - 6),) * 3, indexing="ij")
+    coords = np.stack([i.ravel() + 0.5, j.ravel() + 0.5, k.ravel() + 0.5], 1)
+    got = v.sample(coords)
+    want = data[k.ravel(), j.ravel(), i.ravel()]
+    scale = np.abs(want).max(axis=0)
+    assert (np.abs(got - want).max(axis=0) <= 2e-5 * scale + 1e-12).all()
+    v.free()
+
+
+def test_trilinear_is_exact_at_texel_centres_and_linear_between(oracle):
+    rng = np.random.default_rng(3)
+    n = 12
+    rho = (1.0 + rng.random((n, n, n))).astype(np.float32)
+    v = oracle.volume_from_density(rho, (50.0, 50.0, 50.0), (0.0, 0.0, 750e3), 1)
+    data = v.download()
+    c = np.array([[3.5, 4.5, 5.5], [4.0, 4.5, 5.5], [-3.0, 4.5, 5.5], [100.0, 4.5, 5.5]], np.float32)
+    got = v.sample(c)
+    assert np.array_equal(got[0], data[5, 4, 3])
+    assert np.allclose(got[1], 0.5 * (data[5, 4, 3] + data[5, 4, 4]), rtol=1e-6)
+    assert np.array_equal(got[2], data[5, 4, 0]) and np.array_equal(got[3], data[5, 4, n - 1])   # clamp
+    v.free()
+
+
+def test_thin_lens_magnification(oracle):
+    """An on-plane source at x maps to -M x on the sensor, M = f/(z_obj - f) (paraxial)."""
+    call = scenes.piv_scene(n_particles=1, rays_per_source=2000, mie=False, ray_cone_pitch_ratio=0.2)
+    g = single_lens_camera(lens_model="thin-lens", **scenes.SAMPLE_LENS)
+    call.elements = [g["element"]]
+    call.src_x[:] = 12000.0
+    call.src_y[:] = -7000.0
+    call.src_z[:] = g["z_object"]
+    call.src_radiance = np.ones(1)
+    img, st = oracle.render(call)
+    assert st.rays_on_sensor > 100 and img.sum() > 0
+    M = 105000.0 / (700000.0 - 105000.0)
+    H, W = img.shape
+    rows, cols = np.indices(img.shape)
+    cx, cy = (img * cols).sum() / img.sum(), (img * rows).sum() / img.sum()
+    pitch = 17.0
+    # 4-pixel splat writes to (row-1, col-1) of the continuous pixel coordinate (.cu:2228)
+    x_expect = (-M * 12000.0 + pitch * (W - 1) / 2) / pitch - 1
+    y_expect = (-M * -7000.0 + pitch * (H - 1) / 2) / pitch - 1
+    assert abs(cx - x_expect) < 0.75 and abs(cy - y_expect) < 0.75
+
+
+def test_image_is_linear_in_source_radiance(oracle):
+    call = scenes.bos_scene(n_dots=3, points_per_dot=10, rays_per_source=50)
+    a, _ = oracle.render(call)
+    call.src_radiance = call.src_radiance * 2.0
+    b, _ = oracle.render(call)
+    assert np.allclose(b, 2.0 * a, rtol=1e-6)
