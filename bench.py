@@ -46,11 +46,35 @@ def parse_args():
     return ap.parse_args()
 
 
+def cpu_budget() -> int:
+    """Host threads we may actually use: affinity mask capped by the cgroup CPU quota (a GPU box
+    hands each job a share of the host, e.g. 16 of 128 hardware threads)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    env = os.environ.get("PHOTON_CPU_THREADS")
+    return int(env) if env else n
+
+
 def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source):
     """Time the oracle's ray loop (volume prebuilt, like the GPU side) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle_lib import Oracle
     o = Oracle()
+    o.set_num_threads(cpu_budget())
     n_src = max(1, sample_rays // rays_per_source)
     call = call_factory(n_sources=n_src)
     vol = o.volume_load_nrrd(volume_path, interp)

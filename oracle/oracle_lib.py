@@ -93,6 +93,9 @@ class Oracle:
     def num_threads(self) -> int:
         return int(self.lib.oracle_num_threads())
 
+    def set_num_threads(self, n: int):
+        self.lib.oracle_set_num_threads(int(n))
+
     def rand_table(self, n):
         r1, r2 = np.empty(n, np.float32), np.empty(n, np.float32)
         self.lib.oracle_rand_table(n, _p(r1), _p(r2))

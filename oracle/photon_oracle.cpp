@@ -1259,6 +1259,12 @@ void oracle_det_eval(int fn, int n, const double *x, double *y) {
     }
 }
 
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -233,39 +233,151 @@ __device__ __forceinline__ Ray optical_system(const SceneDev &sc, Ray ray) {
     return ray;
 }
 
-// Gaussian-spot splat: I0*pi/32 * d_erf(col) * d_erf(row) over the pixels within
-// render_fraction*D of the centroid (.cu:1477-1540 / :1660-1730).  The x and y erf differences
-// depend on col resp. row only, so they are evaluated once per column / per (column,row) -- the
-// products are the reference's, term for term.  Each rendered pixel receives the reference's f32
-// increment; the running sum is kept in f64 (one global_atomic_add_f64): the reference's
-// atomicAdd(float) in arbitrary order loses up to N*2^-25 relative on a pixel that receives N
-// near-identical increments (BOS dots: N ~ 1e4), far above the 1e-5 parity bar.
-__device__ __forceinline__ int erf_splat(double *image, int W, int H, float d_x, float d_y, double radiance,
-                                         f3 dir, float D, float render_fraction) {
+// ---------------------------------------------------------------------------------------------
+// Gaussian-spot (erf) splat: I0*pi/32 * d_erf(col) * d_erf(row) over the pixels within
+// render_fraction*D of the centroid (.cu:1477-1540 / :1660-1730).
+//
+// Each rendered pixel receives the reference's f32 increment; the running sum is kept in f64: the
+// reference's atomicAdd(float) in arbitrary order loses up to N*2^-25 relative on a pixel that
+// receives N near-identical increments (BOS dots: N ~ 1e4), far above the 1e-5 parity bar.
+//
+// The 64 rays of a wave come from one or two neighbouring sources, so their spots cover the same
+// few pixels: issued per lane, the ~16 atomics of each ray all collide (measured: the sensor stage
+// 82 % issue-stalled on atomics).  erf_splat_wave therefore works per 8x8 pixel TILE: every lane
+// evaluates its contribution to the tile's 64 pixels (the erf differences depend on the column
+// resp. row only: 16 + 16 erf per tile), a 6-stage butterfly reduce-scatters the 64 x 64 values
+// across the wave so that each lane ends up owning ONE pixel's sum, and the wave issues a single
+// atomic instruction with 64 distinct addresses.  Waves whose spots spread over more than
+// kSplatTiles tiles fall back to per-lane atomics.  Values are the reference's, term for term; only
+// the (f64) summation order differs.
+// ---------------------------------------------------------------------------------------------
+struct SplatReq {
+    bool valid;                 // this lane has a ray to splat
+    float X, Y, D, rfD;         // centroid (pixel units), spot diameter, render_fraction * D
+    double scale;               // I0 * pi / 32
+    int c0, c1, r0, r1;         // the reference's render window
+};
+
+__device__ __forceinline__ SplatReq erf_splat_prepare(bool valid, float d_x, float d_y, double radiance, f3 dir, float D,
+                                                      float render_fraction) {
+    SplatReq q;
+    q.valid = valid;
     const double pi = 3.141592653589793;
     const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
     const float ca = photon_det_cosf(alpha);
     const double cos4 = ca * ca * ca * ca;
-    const float X = d_x - 0.5, Y = d_y - 0.5;
+    q.X = d_x - 0.5; q.Y = d_y - 0.5;
     const float I0 = (float)(radiance * cos4 * 8.0 / pi);
+    q.D = D;
+    q.rfD = render_fraction * D;
+    q.c0 = (int)floorf(q.X - render_fraction * D); q.c1 = (int)ceilf(q.X + render_fraction * D);
+    q.r0 = (int)floorf(q.Y - render_fraction * D); q.r1 = (int)ceilf(q.Y + render_fraction * D);
+    q.scale = I0 * pi / 32.0;
+    return q;
+}
+
+__device__ __forceinline__ double erf_edge_diff(float sqrt8, int idx, float centre, float D) {
+    return erf(sqrt8 * (idx - centre - 0.5) / D) - erf(sqrt8 * (idx - centre + 0.5) / D);
+}
+
+// per-lane form (fallback): one atomic per rendered pixel
+__device__ __forceinline__ int erf_splat_lane(double *image, int W, int H, const SplatReq &q) {
     const float sqrt8 = sqrtf(8.0f);
-    const int c0 = (int)floorf(X - render_fraction * D), c1 = (int)ceilf(X + render_fraction * D);
-    const int r0 = (int)floorf(Y - render_fraction * D), r1 = (int)ceilf(Y + render_fraction * D);
-    const double scale = I0 * pi / 32.0;
     int taps = 0;
-    for (int col = c0; col <= c1; col++) {
+    for (int col = q.c0; col <= q.c1; col++) {
         if (col < 0 || col > W - 1) continue;
-        const double ex = erf(sqrt8 * (col - X - 0.5) / D) - erf(sqrt8 * (col - X + 0.5) / D);
-        const double sx = scale * ex;
-        for (int row = r0; row <= r1; row++) {
-            const float rad = sqrtf((col - X) * (col - X) + (row - Y) * (row - Y));
-            if (!(row >= 0 && row <= H - 1 && rad <= render_fraction * D)) continue;
-            const double ey = erf(sqrt8 * (row - Y - 0.5) / D) - erf(sqrt8 * (row - Y + 0.5) / D);
-            const float inc = (float)(sx * ey);
+        const double sx = q.scale * erf_edge_diff(sqrt8, col, q.X, q.D);
+        for (int row = q.r0; row <= q.r1; row++) {
+            const float rad = sqrtf((col - q.X) * (col - q.X) + (row - q.Y) * (row - q.Y));
+            if (!(row >= 0 && row <= H - 1 && rad <= q.rfD)) continue;
+            const float inc = (float)(sx * erf_edge_diff(sqrt8, row, q.Y, q.D));
             atomicAdd(&image[(size_t)row * W + col], (double)inc);
             taps++;
         }
     }
+    return taps;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 32 values per lane -> each lane keeps the sum over the wave of value (lane >> 1) & 31
+// (lanes 2p and 2p+1 both end with pixel p's total).
+__device__ __forceinline__ double reduce_scatter32(const double (&a)[32], int lane) {
+    double b[16], c[8], d[4], e[2];
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4, h1 = lane & 2;
+#pragma unroll
+    for (int j = 0; j < 16; j++) b[j] = (h5 ? a[16 + j] : a[j]) + __shfl_xor(h5 ? a[j] : a[16 + j], 32, 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) c[j] = (h4 ? b[8 + j] : b[j]) + __shfl_xor(h4 ? b[j] : b[8 + j], 16, 64);
+#pragma unroll
+    for (int j = 0; j < 4; j++) d[j] = (h3 ? c[4 + j] : c[j]) + __shfl_xor(h3 ? c[j] : c[4 + j], 8, 64);
+#pragma unroll
+    for (int j = 0; j < 2; j++) e[j] = (h2 ? d[2 + j] : d[j]) + __shfl_xor(h2 ? d[j] : d[2 + j], 4, 64);
+    double r = (h1 ? e[1] : e[0]) + __shfl_xor(h1 ? e[0] : e[1], 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+constexpr int kSplatTiles = 6;
+
+// Must be called by all 64 lanes of the wave.  Returns this lane's number of rendered pixels.
+__device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const SplatReq &q) {
+    const unsigned long long any = __ballot(q.valid);
+    if (any == 0) return 0;
+    const int big = 0x3fffffff;
+    const int cmin = wave_min_i(q.valid ? q.c0 : big), cmax = wave_max_i(q.valid ? q.c1 : -big);
+    const int rmin = wave_min_i(q.valid ? q.r0 : big), rmax = wave_max_i(q.valid ? q.r1 : -big);
+    const int tiles_x = (cmax - cmin) / 8 + 1, tiles_y = (rmax - rmin) / 8 + 1;
+    if (tiles_x * tiles_y > kSplatTiles) return q.valid ? erf_splat_lane(image, W, H, q) : 0;    // wave-uniform branch
+    const int lane = threadIdx.x & 63;
+    const float sqrt8 = sqrtf(8.0f);
+    int taps = 0;
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const int tc = cmin + 8 * tx, tr = rmin + 8 * ty;           // tile origin (wave-uniform)
+            // does this lane's window touch the tile at all?
+            const bool touch = q.valid && q.c0 <= tc + 7 && q.c1 >= tc && q.r0 <= tr + 7 && q.r1 >= tr;
+            if (__ballot(touch) == 0) continue;                         // wave-uniform
+            double sx[8], ey[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                sx[i] = touch ? q.scale * erf_edge_diff(sqrt8, tc + i, q.X, q.D) : 0.0;
+                ey[i] = touch ? erf_edge_diff(sqrt8, tr + i, q.Y, q.D) : 0.0;
+            }
+            double mine[2];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                double a[32];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                    for (int cc = 0; cc < 8; cc++) {
+                        const int col = tc + cc, row = tr + 4 * half + rr;
+                        const float rad = sqrtf((col - q.X) * (col - q.X) + (row - q.Y) * (row - q.Y));
+                        const bool render = touch && col >= q.c0 && col <= q.c1 && row >= q.r0 && row <= q.r1 &&
+                                            col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1 && rad <= q.rfD;
+                        const float inc = (float)(sx[cc] * ey[4 * half + rr]);
+                        a[rr * 8 + cc] = render ? (double)inc : 0.0;
+                        taps += render ? 1 : 0;
+                    }
+                mine[half] = reduce_scatter32(a, lane);
+            }
+            // lanes 2p / 2p+1 own pixel p of the upper / lower half-tile: 64 distinct addresses
+            const int p = lane >> 1, half = lane & 1;
+            const int col = tc + (p & 7), row = tr + 4 * half + (p >> 3);
+            const double v = half ? mine[1] : mine[0];
+            if (v != 0.0 && col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1)
+                atomicAdd(&image[(size_t)row * W + col], v);
+        }
     return taps;
 }
 
@@ -276,23 +388,23 @@ __device__ __forceinline__ f3 sensor_hit(const Ray &ray, float a, float b, float
     return ray.pos + dir * t;
 }
 
-// intersect_sensor_02 (.cu:1383-1543): erf splat, x axis flipped.  Returns final position.
-__device__ __forceinline__ f3 sensor_diffraction(double *image, const Ray &ray, const camera_design_t &cam, int &taps) {
+// intersect_sensor_02 (.cu:1383-1543): sensor hit, x axis flipped; fills the splat request.
+// Returns the final position (NaN = outside the sensor, no splat).
+__device__ __forceinline__ f3 sensor_diffraction(const Ray &ray, const camera_design_t &cam, SplatReq &req) {
     const f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
     const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
     const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
     const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;
     const float d_y = (hit.y - p1y) / cam.pixel_pitch;
     if (d_x >= cam.x_pixel_number || d_y >= cam.y_pixel_number || d_x < 0 || d_y < 0) return nan3();
-    taps += erf_splat(image, cam.x_pixel_number, cam.y_pixel_number, d_x, d_y, ray.radiance, ray.dir,
-                      cam.diffraction_diameter, 0.75f);
+    req = erf_splat_prepare(true, d_x, d_y, ray.radiance, ray.dir, cam.diffraction_diameter, 0.75f);
     return hit;
 }
 
 // create_apparent_image (.cu:1545-1733): back-project to the object plane, scale by the
 // thin-lens magnification, splat with render_fraction 1.
-__device__ __forceinline__ f3 apparent_image(double *image, const Ray &ray, const camera_design_t &cam,
-                                             float z_object, float z_offset, const element_data_t &e, int &taps) {
+__device__ __forceinline__ f3 apparent_image(const Ray &ray, const camera_design_t &cam, float z_object, float z_offset,
+                                             const element_data_t &e, SplatReq &req) {
     const f3 dir = -ray.dir;
     f3 hit = sensor_hit(ray, 0.0f, 0.0f, -1.0f, z_object, dir);
     const float focal = e.element_properties.thin_lens_focal_length;
@@ -304,8 +416,7 @@ __device__ __forceinline__ f3 apparent_image(double *image, const Ray &ray, cons
     const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;
     const float d_y = (hit.y - p1y) / cam.pixel_pitch;
     if (d_x >= cam.x_pixel_number || d_y >= cam.y_pixel_number || d_x < 0 || d_y < 0) return nan3();
-    taps += erf_splat(image, cam.x_pixel_number, cam.y_pixel_number, d_x, d_y, ray.radiance, dir,
-                      cam.diffraction_diameter, 1.0f);
+    req = erf_splat_prepare(true, d_x, d_y, ray.radiance, dir, cam.diffraction_diameter, 1.0f);
     return hit;
 }
 

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     int taps = 0;
     unsigned on_sensor = 0;
+    SplatReq req;                                                       // erf splat, done wave-cooperatively below
+    req.valid = false;
+    req.X = req.Y = req.D = req.rfD = 0.f; req.scale = 0.0; req.c0 = req.c1 = req.r0 = req.r1 = 0;
     if (r < n_rays) {
         Ray ray;
         bool alive = true;
@@ -299,14 +302,14 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
             }
             if (sc.elems[0].element_type == 'n') {                      // .cu:2143-2158
                 const float z_obj = sc.object_distance + sc.z_offset;
-                fin = apparent_image(image, ray, sc.cam, z_obj, sc.z_offset, sc.elems[0], taps);
+                fin = apparent_image(ray, sc.cam, z_obj, sc.z_offset, sc.elems[0], req);
                 have_fin = true;
                 on_sensor = !isnan(fin.x);
             } else {
                 ray = optical_system(sc, ray);
                 if (!(isnan3(ray.dir) || isnan3(ray.pos))) {            // .cu:2172-2176
                     if (sc.cam.implement_diffraction) {
-                        fin = sensor_diffraction(image, ray, sc.cam, taps);
+                        fin = sensor_diffraction(ray, sc.cam, req);
                         have_fin = true;
                         on_sensor = !isnan(fin.x);
                     } else {
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
             dump.final_pos[3 * r] = fin.x; dump.final_pos[3 * r + 1] = fin.y; dump.final_pos[3 * r + 2] = fin.z;
         }
     }
+    taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req);      // all 64 lanes
     wave_add(&counters[CNT_TAPS], (unsigned long long)taps);
     wave_add(&counters[CNT_ON_SENSOR], (unsigned long long)on_sensor);
 }
