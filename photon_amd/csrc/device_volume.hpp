@@ -347,9 +347,17 @@ __device__ __forceinline__ f4 cubic_taps_uniform(const f4 *__restrict__ tex, int
 // The same sum with per-lane, clamped addressing (volume faces, incoherent waves).  Deliberately
 // NOT inlined: it is the rare path, and inlined at three call sites its 64 loads in flight would
 // set the register budget (and so the occupancy) of the whole march kernel.
-struct CubicWeights { float wx[4], wy[4], wz[4]; };
-__device__ __attribute__((noinline)) f4 cubic_taps_gather_fn(const f4 *__restrict__ tex, int nx, int ny, int nz, int i,
-                                                             int j, int k, CubicWeights w) {
+// (It recomputes the B-spline weights from the coordinate -- same operations, same values -- so a
+// call site only has to pass three floats.)
+__device__ __attribute__((noinline)) f4 cubic_gather_fn(const f4 *__restrict__ tex, int nx, int ny, int nz, float x,
+                                                        float y, float z) {
+    const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
+    const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
+    float wx[4], wy[4], wz[4];
+    bspline_weights(xg - fi, wx[0], wx[1], wx[2], wx[3]);
+    bspline_weights(yg - fj, wy[0], wy[1], wy[2], wy[3]);
+    bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
     const size_t W = nx, WH = (size_t)nx * ny;
     f4 acc = f4{0, 0, 0, 0};
 #pragma unroll 1
@@ -361,29 +369,21 @@ __device__ __attribute__((noinline)) f4 cubic_taps_gather_fn(const f4 *__restric
             const f4 *row = slab + clampi(j - 1 + b, 0, ny - 1) * W;
             const f4 t0 = ldtexel(row + clampi(i - 1, 0, nx - 1)), t1 = ldtexel(row + clampi(i, 0, nx - 1));
             const f4 t2 = ldtexel(row + clampi(i + 1, 0, nx - 1)), t3 = ldtexel(row + clampi(i + 2, 0, nx - 1));
-            f4 r = f4{w.wx[0] * t0.x, w.wx[0] * t0.y, w.wx[0] * t0.z, w.wx[0] * t0.w};
-            r = f4{fmaf(w.wx[1], t1.x, r.x), fmaf(w.wx[1], t1.y, r.y), fmaf(w.wx[1], t1.z, r.z), fmaf(w.wx[1], t1.w, r.w)};
-            r = f4{fmaf(w.wx[2], t2.x, r.x), fmaf(w.wx[2], t2.y, r.y), fmaf(w.wx[2], t2.z, r.z), fmaf(w.wx[2], t2.w, r.w)};
-            r = f4{fmaf(w.wx[3], t3.x, r.x), fmaf(w.wx[3], t3.y, r.y), fmaf(w.wx[3], t3.z, r.z), fmaf(w.wx[3], t3.w, r.w)};
-            const float wyb = w.wy[b];
+            f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
+            r = f4{fmaf(wx[1], t1.x, r.x), fmaf(wx[1], t1.y, r.y), fmaf(wx[1], t1.z, r.z), fmaf(wx[1], t1.w, r.w)};
+            r = f4{fmaf(wx[2], t2.x, r.x), fmaf(wx[2], t2.y, r.y), fmaf(wx[2], t2.z, r.z), fmaf(wx[2], t2.w, r.w)};
+            r = f4{fmaf(wx[3], t3.x, r.x), fmaf(wx[3], t3.y, r.y), fmaf(wx[3], t3.z, r.z), fmaf(wx[3], t3.w, r.w)};
+            const float wyb = wy[b];
             if (b == 0) plane = f4{wyb * r.x, wyb * r.y, wyb * r.z, wyb * r.w};
             else plane = f4{fmaf(wyb, r.x, plane.x), fmaf(wyb, r.y, plane.y), fmaf(wyb, r.z, plane.z),
                             fmaf(wyb, r.w, plane.w)};
         }
-        const float wzc = w.wz[c];
+        const float wzc = wz[c];
         if (c == 0) acc = f4{wzc * plane.x, wzc * plane.y, wzc * plane.z, wzc * plane.w};
         else acc = f4{fmaf(wzc, plane.x, acc.x), fmaf(wzc, plane.y, acc.y), fmaf(wzc, plane.z, acc.z),
                       fmaf(wzc, plane.w, acc.w)};
     }
     return acc;
-}
-__device__ __forceinline__ f4 cubic_taps_gather(const f4 *__restrict__ tex, int nx, int ny, int nz, int i, int j,
-                                                int k, const float (&wx)[4], const float (&wy)[4],
-                                                const float (&wz)[4]) {
-    CubicWeights w;
-#pragma unroll
-    for (int a = 0; a < 4; a++) { w.wx[a] = wx[a]; w.wy[a] = wy[a]; w.wz[a] = wz[a]; }
-    return cubic_taps_gather_fn(tex, nx, ny, nz, i, j, k, w);
 }
 
 __device__ __forceinline__ f4 tex3d_cubic_packed(const VolumeDev &v, const f4 *__restrict__ tex, float x, float y,
@@ -415,7 +415,7 @@ __device__ __forceinline__ f4 tex3d_cubic_packed(const VolumeDev &v, const f4 *_
         }
     }
     if (!interior || !done)             // volume faces, or an incoherent wave (> kPackedGroups blocks)
-        acc = cubic_taps_gather(tex, v.nx, v.ny, v.nz, bi, bj, bk, wx, wy, wz);
+        acc = cubic_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);
     return acc;
 }
 

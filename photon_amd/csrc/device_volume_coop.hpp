@@ -29,41 +29,41 @@ namespace photon {
 
 constexpr int kCoopGroups = 4;          // distinct texel blocks served cooperatively per sample
 
-// 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c).
-// Texels are handled as 4-wide vectors (one ds_read_b128 each); the per-component operation
-// sequence is exactly the scalar fmaf chain of tex3d_cubic().
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4f splat4(float s) { return v4f{s, s, s, s}; }
-__device__ __forceinline__ v4f fma4(float w, v4f t, v4f acc) { return __builtin_elementwise_fma(splat4(w), t, acc); }
-
-// sum over one z-slab: 16 texels, x innermost
-__device__ __forceinline__ v4f cubic_slab_lds(const v4f *q, const float (&wx)[4], const float (&wy)[4]) {
-    v4f plane = splat4(0.f);
+// 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each
+// texel is one ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues in
+// 4 cycles against 2 for v_fma_f32 (measured, build/ubench/fma_rate.hip), so packing buys no
+// throughput and costs the (w,w) operand splats; the library is built with -fno-slp-vectorize.
+__device__ __forceinline__ f4 cubic_slab_lds(const f4 *q, const float (&wx)[4], const float (&wy)[4]) {
+    f4 plane = f4{0, 0, 0, 0};
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-        const v4f *row = q + b * 4;
-        v4f r = splat4(wx[0]) * row[0];
-        r = fma4(wx[1], row[1], r);
-        r = fma4(wx[2], row[2], r);
-        r = fma4(wx[3], row[3], r);
-        plane = (b == 0) ? splat4(wy[0]) * r : fma4(wy[b], r, plane);
+        const f4 *row = q + b * 4;
+        const f4 t0 = ldtexel(row), t1 = ldtexel(row + 1), t2 = ldtexel(row + 2), t3 = ldtexel(row + 3);
+        f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
+        r = f4{fmaf(wx[1], t1.x, r.x), fmaf(wx[1], t1.y, r.y), fmaf(wx[1], t1.z, r.z), fmaf(wx[1], t1.w, r.w)};
+        r = f4{fmaf(wx[2], t2.x, r.x), fmaf(wx[2], t2.y, r.y), fmaf(wx[2], t2.z, r.z), fmaf(wx[2], t2.w, r.w)};
+        r = f4{fmaf(wx[3], t3.x, r.x), fmaf(wx[3], t3.y, r.y), fmaf(wx[3], t3.z, r.z), fmaf(wx[3], t3.w, r.w)};
+        if (b == 0) plane = f4{wy[0] * r.x, wy[0] * r.y, wy[0] * r.z, wy[0] * r.w};
+        else plane = f4{fmaf(wy[b], r.x, plane.x), fmaf(wy[b], r.y, plane.y), fmaf(wy[b], r.z, plane.z),
+                        fmaf(wy[b], r.w, plane.w)};
     }
     return plane;
 }
 
 __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4], const float (&wy)[4],
                                              const float (&wz)[4]) {
-    const v4f *q = reinterpret_cast<const v4f *>(blk);
-    v4f acc = splat4(wz[0]) * cubic_slab_lds(q, wx, wy);
+    f4 p = cubic_slab_lds(blk, wx, wy);
+    f4 acc = f4{wz[0] * p.x, wz[0] * p.y, wz[0] * p.z, wz[0] * p.w};
     // A compiler memory barrier between z-slabs: without it the scheduler hoists all 64 texel
     // reads to the top (256 VGPRs in flight, one wave per SIMD).  One slab = 16 reads = 64 VGPRs
-    // covers the LDS latency and leaves room for more waves per SIMD.
+    // covers the LDS latency.
 #pragma unroll
     for (int c = 1; c < 4; c++) {
         asm volatile("" ::: "memory");
-        acc = fma4(wz[c], cubic_slab_lds(q + c * 16, wx, wy), acc);
+        p = cubic_slab_lds(blk + c * 16, wx, wy);
+        acc = f4{fmaf(wz[c], p.x, acc.x), fmaf(wz[c], p.y, acc.y), fmaf(wz[c], p.z, acc.z), fmaf(wz[c], p.w, acc.w)};
     }
-    return f4{acc.x, acc.y, acc.z, acc.w};
+    return acc;
 }
 
 // Must be called by ALL 64 lanes of the wave (wave-uniform control flow); `need` says whether this
@@ -102,7 +102,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (!done) acc = cubic_taps_gather(tex, v.nx, v.ny, v.nz, bi, bj, bk, wx, wy, wz);     // incoherent wave
+    if (!done) acc = cubic_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);                       // incoherent wave
     return acc;
 }
 
