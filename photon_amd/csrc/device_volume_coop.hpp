@@ -27,6 +27,10 @@
 
 namespace photon {
 
+#ifndef PHOTON_LDS_ROWS_IN_FLIGHT
+#define PHOTON_LDS_ROWS_IN_FLIGHT 4      // texel rows (x4 texels x4 VGPRs) read ahead of the FMAs: 4 = one z-slab
+#endif
+
 constexpr int kCoopGroups = 4;          // distinct texel blocks served cooperatively per sample
 
 // 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each
@@ -37,6 +41,7 @@ __device__ __forceinline__ f4 cubic_slab_lds(const f4 *q, const float (&wx)[4], 
     f4 plane = f4{0, 0, 0, 0};
 #pragma unroll
     for (int b = 0; b < 4; b++) {
+        if (PHOTON_LDS_ROWS_IN_FLIGHT == 2 && b == 2) asm volatile("" ::: "memory");
         const f4 *row = q + b * 4;
         const f4 t0 = ldtexel(row), t1 = ldtexel(row + 1), t2 = ldtexel(row + 2), t3 = ldtexel(row + 3);
         f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};

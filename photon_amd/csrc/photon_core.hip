@@ -234,8 +234,12 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
 // Stage 1 (density gradients on): generate the ray, move it to the volume's world frame, march
 // it, move it back (parallel_ray_tracing.cu:2004-2131), store the state SoA.  One lane per ray,
 // rays source-major so the 64 lanes of a wave start from (almost) the same point.
+// launch bound: 4 waves per SIMD (<= 128 VGPRs).  A wave issues at most one VALU instruction per
+// ~4 cycles, the SIMD one per 2: the march needs >= 3-4 resident waves to keep the VALU fed
+// (measured on C3 cubic: 142 VGPR / 3 waves 100.8 ms, 128 VGPR / 4 waves 93.2 ms, 96 VGPR / 5 waves
+// spills: 165 ms).
 template <int ALGO, int INTERP>
-__global__ __launch_bounds__(256) void march_kernel(SceneDev sc, VolumeDev vol, const f4 *__restrict__ tex,
+__global__ __launch_bounds__(256, 4) void march_kernel(SceneDev sc, VolumeDev vol, const f4 *__restrict__ tex,
                                                     long long src_begin, unsigned n_rays, RayStateDev st,
                                                     unsigned long long *__restrict__ counters) {
     __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
