@@ -84,7 +84,6 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
     const int lane = threadIdx.x & 63;
     const int ta = lane & 3, tb = (lane >> 2) & 3, tc = lane >> 4;
-    const size_t W = v.nx, WH = (size_t)v.nx * v.ny;
     f4 acc = f4{0, 0, 0, 0};
     bool done = !need;
 #pragma unroll 1
@@ -97,7 +96,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         // one coalesced-ish load instruction for the whole block: 16 rows of 64 contiguous bytes
         const int tx = clampi(ci - 1 + ta, 0, v.nx - 1), ty = clampi(cj - 1 + tb, 0, v.ny - 1),
                   tz = clampi(ck - 1 + tc, 0, v.nz - 1);
-        const f4 t = ldtexel(tex + tz * WH + ty * W + tx);
+        const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));       // < 2^31 texels (checked on the host)
         __builtin_amdgcn_wave_barrier();
         *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
         __builtin_amdgcn_wave_barrier();
@@ -119,7 +118,6 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
     const int lane = threadIdx.x & 63;
     const int ta = lane & 1, tb = (lane >> 1) & 1, tc = (lane >> 2) & 1;
-    const size_t W = v.nx, WH = (size_t)v.nx * v.ny;
     f4 acc = f4{0, 0, 0, 0};
     bool done = !need;
 #pragma unroll 1
@@ -133,7 +131,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                   tz = clampi(ck + tc, 0, v.nz - 1);
         __builtin_amdgcn_wave_barrier();
         if (lane < 8) {
-            const f4 t = ldtexel(tex + tz * WH + ty * W + tx);
+            const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
             *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
         }
         __builtin_amdgcn_wave_barrier();
@@ -149,6 +147,46 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     }
     if (!done) acc = linear_taps<true>(tex, v.nx, v.ny, v.nz, bi, bj, bk, a, b, c);
     return acc;
+}
+
+// Loop-invariant, wave-uniform quantities of the march, pinned into SGPRs (readfirstlane): f32
+// arithmetic has no scalar ALU on gfx950, so without this the compiler keeps them in VGPRs -- ~20
+// registers per lane that cost a whole wave of occupancy (or get spilled into the hot loop).
+struct MarchU {
+    float minx, miny, minz, maxx, maxy, maxz;   // box
+    float sx, sy, sz;                           // 1 / (max - min)
+    float nxm2, nym2, nzm2;                     // (float)(n - 2)
+    float fnx, fny, fnz;                        // (float)n
+    float step, data_min, spin_step;            // h, min(n-1), h / (1 + data_min)
+    int nx, ny, nz;
+};
+__device__ __forceinline__ float uniformf(float x) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+__device__ __forceinline__ MarchU make_march_consts(const VolumeDev &v, f3 scale) {
+    MarchU u;
+    u.minx = uniformf(v.min_bound.x); u.miny = uniformf(v.min_bound.y); u.minz = uniformf(v.min_bound.z);
+    u.maxx = uniformf(v.max_bound.x); u.maxy = uniformf(v.max_bound.y); u.maxz = uniformf(v.max_bound.z);
+    u.sx = uniformf(scale.x); u.sy = uniformf(scale.y); u.sz = uniformf(scale.z);
+    u.nxm2 = uniformf((float)(v.nx - 2)); u.nym2 = uniformf((float)(v.ny - 2)); u.nzm2 = uniformf((float)(v.nz - 2));
+    u.fnx = uniformf((float)v.nx); u.fny = uniformf((float)v.ny); u.fnz = uniformf((float)v.nz);
+    u.step = uniformf(v.step_size); u.data_min = uniformf(v.data_min);
+    u.spin_step = uniformf(v.step_size / (1 + v.data_min));
+    u.nx = v.nx; u.ny = v.ny; u.nz = v.nz;
+    return u;
+}
+// calculate_lookup_index / ray_inside_box / access_refractive_index (.h:195-277) on the constants
+__device__ __forceinline__ f3 lookup_index_u(f3 pos, const MarchU &u) {
+    const f3 off = mk3(pos.x - u.minx, pos.y - u.miny, pos.z - u.minz);
+    const f3 fn = mk3(u.sx * off.x, u.sy * off.y, u.sz * off.z);
+    return mk3(1 + fn.x * u.nxm2, 1 + fn.y * u.nym2, 1 + fn.z * u.nzm2);
+}
+__device__ __forceinline__ bool can_access_u(const MarchU &u, f3 l) {
+    return !(l.x < 0 || l.y < 0 || l.z < 0 || l.x >= u.fnx || l.y >= u.fny || l.z >= u.fnz);
+}
+__device__ __forceinline__ bool inside_box_u(f3 p, const MarchU &u, f3 l) {
+    if (p.x < u.minx || p.y < u.miny || p.z < u.minz || p.x >= u.maxx || p.y >= u.maxy || p.z >= u.maxz) return false;
+    return can_access_u(u, l);
 }
 
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
@@ -181,21 +219,24 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
 template <int INTERP>
 __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
                                          const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc) {
+    const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0;
     f4 val_prev = f4{0, 0, 0, 0};
+    f3 T_n = rdir, A = mk3(0, 0, 0), B = mk3(0, 0, 0), spos = rpos;     // only meaningful while `go`
+    float delta_t = 0.f, current_n = 1.f;
     while (__ballot(active) != 0) {                             // wave-uniform loop
-        // ---------------- sample A at R_n ----------------
+        // ---------------- sample A at R_n (= rpos) ----------------
         bool need = false;
         f3 lookup = mk3(0, 0, 0);
         if (active) {
             if (loop_ctr > kLoopMax) {
                 active = false;
             } else {
-                lookup = lookup_index(rpos, v, scale);
-                if (!inside_box(rpos, v, lookup) && loop_ctr != 0) {
+                lookup = lookup_index_u(rpos, u);
+                if (!inside_box_u(rpos, u, lookup) && loop_ctr != 0) {
                     active = false;                             // left the volume: done
-                } else if (!can_access(v, lookup)) {            // .h:1043-1049
-                    rpos = rpos + v.step_size / (1 + v.data_min) * rdir;
+                } else if (!can_access_u(u, lookup)) {          // .h:1043-1049
+                    rpos = rpos + u.spin_step * rdir;
                     if (++spins > kSpinMax) active = false;
                 } else {
                     need = true;
@@ -204,20 +245,18 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
         }
         f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
         bool go = false;                                        // lane continues to samples B and C
-        f3 R_n = rpos, T_n = rdir, A = mk3(0, 0, 0), B = mk3(0, 0, 0), spos = rpos;
-        float delta_t = 0.f, current_n = 1.f;
         if (need) {
-            if (INTERP == 2 && val.w < v.data_min) {            // .h:1220-1227
-                rpos = rpos + v.step_size / (1 + v.data_min) * rdir;
+            if (INTERP == 2 && val.w < u.data_min) {            // .h:1220-1227
+                rpos = rpos + u.spin_step * rdir;
                 if (++spins > kSpinMax) active = false;
             } else {
                 loop_ctr += 1;
                 val.w += 1;
                 current_n = val.w;
-                delta_t = v.step_size / val.w;
+                delta_t = u.step / val.w;
                 T_n = val.w * rdir;
                 A = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
-                spos = R_n + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;       // .h:1088
+                spos = rpos + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;      // .h:1088
                 if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
                 go = true;
             }
@@ -225,31 +264,30 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
         // ---------------- sample B ----------------
         need = false;
         if (go) {
-            lookup = lookup_index(spos, v, scale);
-            if (!inside_box(spos, v, lookup)) { active = false; go = false; }       // .h:1094-1101
+            lookup = lookup_index_u(spos, u);
+            if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1094-1101
             else need = true;
         }
         val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
         if (need) {
             val.w += 1;
             B = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
-            spos = R_n + delta_t * T_n + (0.5f * delta_t) * B;                      // .h:1131
+            spos = rpos + delta_t * T_n + (0.5f * delta_t) * B;                     // .h:1131
             if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
         }
         // ---------------- sample C ----------------
         need = false;
         if (go) {
-            lookup = lookup_index(spos, v, scale);
-            if (!inside_box(spos, v, lookup)) { active = false; go = false; }       // .h:1135-1141
+            lookup = lookup_index_u(spos, u);
+            if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1135-1141
             else need = true;
         }
         val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
         if (need) {
             val.w += 1;
             const f3 C = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
-            R_n = R_n + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));        // .h:1169
+            rpos = rpos + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));      // .h:1169
             T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);                      // .h:1170
-            rpos = R_n;
             rdir = normalize(T_n / (INTERP == 1 ? current_n : val.w));              // .h:1178 / 1276
             if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
             mc.iterations++;

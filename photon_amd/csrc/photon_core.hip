@@ -6,8 +6,8 @@
 //   host   start_ray_tracing / photon_*      argument marshalling, NRRD parse, chunk loop, dumps
 //   GPU    build_volume_kernel               density -> (grad n, n-1) float4 texels
 //          prefilter_lines_kernel x3         cubic B-spline prefilter, per channel (x, y, z lines)
-//          march_kernel<ALGO,INTERP>         ray generation + Mie lookup + world transform +
-//                                            Euler/RK4 march through the volume -> SoA ray state
+//          raygen_kernel                     ray generation + Mie lookup + world transform -> SoA state
+//          march_kernel<ALGO,INTERP>         Euler/RK4 march through the volume, in place on the state
 //          sensor_kernel<FROM_STATE>         (ray generation |) lens / aperture / apparent image
 //                                            + erf or 4-pixel splat, f64 atomics into a private
 //                                            accumulator
@@ -231,42 +231,47 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
 // the two ray-tracing kernels
 // =============================================================================================
 
-// Stage 1 (density gradients on): generate the ray, move it to the volume's world frame, march
-// it, move it back (parallel_ray_tracing.cu:2004-2131), store the state SoA.  One lane per ray,
-// rays source-major so the 64 lanes of a wave start from (almost) the same point.
+// Stage 1a (density gradients on): generate the ray and move it into the volume's world frame
+// (parallel_ray_tracing.cu:2004-2082).  Kept apart from the march so that the hot kernel carries
+// neither the scene description (a kilobyte of kernel arguments pinned in SGPRs) nor the
+// double-precision ray-generation code in its register budget.
+__global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st) {
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const unsigned rps = (unsigned)sc.rays_per_source;
+    const Ray ray = generate_ray(sc, (int)(src_begin + r / rps), (int)(r % rps));
+    f3 p = ray.pos, d = ray.dir;
+    p.z = (float)(p.z - (sc.z_offset + 750e3));                         // .cu:2045
+    p = matvec(sc.cam.inverse_rotation_matrix, p);                      // camera -> world
+    d = matvec(sc.cam.inverse_rotation_matrix, d);
+    st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
+    st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+    st.radiance[r] = ray.radiance;
+}
+
+// Stage 1b: march the rays through the volume, in place on the SoA state (world frame).  One lane
+// per ray, rays source-major so the 64 lanes of a wave start from (almost) the same point.
 // launch bound: 4 waves per SIMD (<= 128 VGPRs).  A wave issues at most one VALU instruction per
 // ~4 cycles, the SIMD one per 2: the march needs >= 3-4 resident waves to keep the VALU fed
 // (measured on C3 cubic: 142 VGPR / 3 waves 100.8 ms, 128 VGPR / 4 waves 93.2 ms, 96 VGPR / 5 waves
 // spills: 165 ms).
 template <int ALGO, int INTERP>
-__global__ __launch_bounds__(256, 4) void march_kernel(SceneDev sc, VolumeDev vol, const f4 *__restrict__ tex,
-                                                    long long src_begin, unsigned n_rays, RayStateDev st,
-                                                    unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(256, ALGO == 2 ? 4 : 1) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
+                                                       RayStateDev st, unsigned long long *__restrict__ counters) {
     __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
     const bool has_ray = r < n_rays;
     MarchCount mc{0, 0};
     f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
-    double radiance = 0.0;
     if (has_ray) {
-        const unsigned rps = (unsigned)sc.rays_per_source;
-        const int source = (int)(src_begin + r / rps);
-        const int local_ray = (int)(r % rps);
-        const Ray ray = generate_ray(sc, source, local_ray);
-        p = ray.pos; d = ray.dir; radiance = ray.radiance;
-        p.z = (float)(p.z - (sc.z_offset + 750e3));                     // .cu:2045
-        p = matvec(sc.cam.inverse_rotation_matrix, p);                  // camera -> world
-        d = matvec(sc.cam.inverse_rotation_matrix, d);
+        p = mk3(st.px[r], st.py[r], st.pz[r]);
+        d = mk3(st.dx[r], st.dy[r], st.dz[r]);
     }
     trace_volume_coop<ALGO, INTERP>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc);   // all 64 lanes
     if (has_ray) {
-        p = matvec(sc.cam.rotation_matrix, p);                          // world -> camera
-        d = normalize(matvec(sc.cam.rotation_matrix, d));
-        p.z = (float)(p.z + (sc.z_offset + 750e3));                     // .cu:2119
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
-        st.radiance[r] = radiance;
     }
     wave_add(&counters[CNT_ITER], (unsigned long long)mc.iterations);
     wave_add(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
@@ -286,9 +291,14 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
     if (r < n_rays) {
         Ray ray;
         bool alive = true;
-        if (FROM_STATE) {
-            ray.pos = mk3(st.px[r], st.py[r], st.pz[r]);
-            ray.dir = mk3(st.dx[r], st.dy[r], st.dz[r]);
+        if (FROM_STATE) {                                              // back to the camera frame (.cu:2100-2122)
+            f3 p = mk3(st.px[r], st.py[r], st.pz[r]);
+            f3 d = mk3(st.dx[r], st.dy[r], st.dz[r]);
+            p = matvec(sc.cam.rotation_matrix, p);
+            d = normalize(matvec(sc.cam.rotation_matrix, d));
+            p.z = (float)(p.z + (sc.z_offset + 750e3));                 // .cu:2119
+            ray.pos = p;
+            ray.dir = d;
             ray.radiance = st.radiance[r];
             ray.wavelength = sc.beam_wavelength;
             alive = !(isnan3(ray.dir) || isnan3(ray.pos));              // .cu:2125-2129
@@ -735,13 +745,15 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     if (vol) {
         int rc = ensure_workspace(s, n);
         if (rc) return rc;
+        hipLaunchKernelGGL(raygen_kernel, grid, block, 0, stream, s->dev, src_begin, n, s->ws);
+        PH_CHECK(hipGetLastError());
         if (timed) PH_CHECK(hipEventRecord(s->ev[1], stream));
         const int interp = vol->dev.interpolation;
         const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
-        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
-        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
-        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
-        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, s->dev, vol->dev, tex, src_begin, n, s->ws, s->d_counters);
+        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
+        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
+        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
+        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
         PH_CHECK(hipGetLastError());
         if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
         hipLaunchKernelGGL((sensor_kernel<true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
