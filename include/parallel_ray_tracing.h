@@ -126,9 +126,7 @@ typedef struct camera_design_t {
  * Environment knobs (the ABI has no room for new arguments):
  *   PHOTON_INTERP=linear|cubic   volume sampler (default linear = the reference's
  *                                hard-coded interpolation_scheme 1, .cu:3330)
- *   PHOTON_DEVICES=N             shard sources over the first N GPUs, RCCL-reduce image
  *   PHOTON_VERBOSE=1             progress / timing on stdout
- *   PHOTON_NOISE_SEED=u64        seed for the optional noise hooks (reference: time(NULL))
  */
 void start_ray_tracing(float lens_pitch, float image_distance,
                        scattering_data_t *scattering_data_p, char *scattering_type_str,

@@ -31,7 +31,13 @@ namespace photon {
 #define PHOTON_LDS_ROWS_IN_FLIGHT 4      // texel rows (x4 texels x4 VGPRs) read ahead of the FMAs: 4 = one z-slab
 #endif
 
-constexpr int kCoopGroups = 4;          // distinct texel blocks served cooperatively per sample
+#ifndef PHOTON_COOP_GROUPS
+#define PHOTON_COOP_GROUPS 4
+#endif
+#ifndef PHOTON_INTERIOR_FAST
+#define PHOTON_INTERIOR_FAST 0      // measured: the scalar interior test + second code path costs 2.5 % (88.0 vs 90.1 ms)
+#endif
+constexpr int kCoopGroups = PHOTON_COOP_GROUPS;      // distinct texel blocks served cooperatively per sample
 
 // 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each
 // texel is one ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues in
@@ -84,6 +90,8 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
     const int lane = threadIdx.x & 63;
     const int ta = lane & 3, tb = (lane >> 2) & 3, tc = lane >> 4;
+    // this lane's texel of an INTERIOR block, relative to the block's corner texel (no clamping)
+    const int lane_off = ((tc - 1) * v.ny + (tb - 1)) * v.nx + (ta - 1);
     f4 acc = f4{0, 0, 0, 0};
     bool done = !need;
 #pragma unroll 1
@@ -93,10 +101,17 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         const int leader = __ffsll((long long)todo) - 1;
         const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
                   ck = __builtin_amdgcn_readlane(bk, leader);
-        // one coalesced-ish load instruction for the whole block: 16 rows of 64 contiguous bytes
-        const int tx = clampi(ci - 1 + ta, 0, v.nx - 1), ty = clampi(cj - 1 + tb, 0, v.ny - 1),
-                  tz = clampi(ck - 1 + tc, 0, v.nz - 1);
-        const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));       // < 2^31 texels (checked on the host)
+        // one coalesced-ish load instruction for the whole block: 16 rows of 64 contiguous bytes.
+        // Interior blocks (the common case; a scalar test) need no per-texel clamping.
+        unsigned idx;
+        if (PHOTON_INTERIOR_FAST && ci >= 1 && ci + 2 < v.nx && cj >= 1 && cj + 2 < v.ny && ck >= 1 && ck + 2 < v.nz) {
+            idx = (unsigned)((ck * v.ny + cj) * v.nx + ci + lane_off);
+        } else {
+            const int tx = clampi(ci - 1 + ta, 0, v.nx - 1), ty = clampi(cj - 1 + tb, 0, v.ny - 1),
+                      tz = clampi(ck - 1 + tc, 0, v.nz - 1);
+            idx = (unsigned)((tz * v.ny + ty) * v.nx + tx);
+        }
+        const f4 t = ldtexel(tex + idx);                        // < 2^31 texels (checked on the host)
         __builtin_amdgcn_wave_barrier();
         *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
         __builtin_amdgcn_wave_barrier();
@@ -295,6 +310,55 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
     }
 }
 
+// Wave-synchronous Euler integrator (reference: .h:743-950, noise hook not built): one
+// cooperative sample per trip.  Per-ray operation order is that of euler<> in device_volume.hpp.
+template <int INTERP>
+__device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
+                                           const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc) {
+    const MarchU u = make_march_consts(v, scale);
+    int loop_ctr = 0, spins = 0;
+    f4 val_prev = f4{0, 0, 0, 0};
+    while (__ballot(active) != 0) {
+        bool need = false;
+        f3 lookup = mk3(0, 0, 0);
+        if (active) {
+            if (loop_ctr > kLoopMax) {
+                active = false;
+            } else {
+                lookup = lookup_index_u(rpos, u);
+                if (!inside_box_u(rpos, u, lookup) && loop_ctr != 0) {
+                    active = false;
+                } else if (INTERP == 1 && !can_access_u(u, lookup)) {   // only the linear branch guards (.h:821)
+                    rpos = rpos + u.spin_step * rdir;
+                    if (++spins > kSpinMax) active = false;
+                } else {
+                    need = true;
+                }
+            }
+        }
+        const f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        if (need) {
+            if (INTERP == 1) {
+                const float current_n = 1 + val.w;
+                rdir = rdir + u.step * mk3(val.x, val.y, val.z);       // .h:869 (not renormalised)
+                rpos = rpos + u.step / current_n * rdir;                // .h:875
+                val_prev = val;
+                loop_ctr += 1;
+                mc.iterations++;
+            } else if (val.w < u.data_min) {                            // .h:916-923
+                rpos = rpos + u.spin_step * rdir;
+                if (++spins > kSpinMax) active = false;
+            } else {
+                loop_ctr += 1;
+                rdir = normalize(rdir + u.step * mk3(val.x, val.y, val.z));     // .h:931-933
+                const float n = 1 + val.w;
+                rpos = rpos + rdir * u.step / n;                        // .h:939
+                mc.iterations++;
+            }
+        }
+    }
+}
+
 // trace_rays_through_density_gradients (.h:1455-1544), wave-synchronous.  has_ray = this lane
 // carries a ray at all (tail lanes of the last workgroup do not).
 template <int ALGO, int INTERP>
@@ -311,11 +375,8 @@ __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &
         }
         if (active) pos_io = pos;
     }
-    if (ALGO == 1) {
-        if (active) euler<INTERP>(pos_io, dir_io, v, scale, mc);
-    } else {
-        rk4_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc);
-    }
+    if (ALGO == 1) euler_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc);
+    else rk4_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc);
 }
 
 }  // namespace photon

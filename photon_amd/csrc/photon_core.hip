@@ -255,8 +255,11 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 // ~4 cycles, the SIMD one per 2: the march needs >= 3-4 resident waves to keep the VALU fed
 // (measured on C3 cubic: 142 VGPR / 3 waves 100.8 ms, 128 VGPR / 4 waves 93.2 ms, 96 VGPR / 5 waves
 // spills: 165 ms).
+#ifndef PHOTON_MARCH_WAVES
+#define PHOTON_MARCH_WAVES 4
+#endif
 template <int ALGO, int INTERP>
-__global__ __launch_bounds__(256, ALGO == 2 ? 4 : 1) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
+__global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters) {
     __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -487,6 +490,10 @@ int photon_volume_from_density(const float *rho, int nx, int ny, int nz, const d
     const double xmax = xmin + (nx - 1) * spacing[0], ymax = ymin + (ny - 1) * spacing[1];
     const double zmax = zmin + (nz - 1) * spacing[2];
     if (nz > 1024) nz = 1024;
+    if ((unsigned long long)nx * ny * nz >= (1ull << 31)) {
+        fprintf(stderr, "photon: volume of %d x %d x %d texels exceeds the 2^31-texel limit of the samplers\n", nx, ny, nz);
+        return 1;
+    }
     photon_volume *v = new photon_volume();
     const size_t n = (size_t)nx * ny * nz;
     float *d_rho = nullptr, *d_min = nullptr;
