@@ -104,7 +104,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_launcher:         # one process per GPU over RCCL (also exercised at world_size 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     interp = 2 if args.interp == "cubic" else 1
@@ -117,7 +118,7 @@ def main():
         rho, sp, org = scenes.bos_volume(args.volume)
         scenes.write_nrrd(vol_path + ".tmp", rho, sp, org)
         os.replace(vol_path + ".tmp", vol_path)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
 
     def make_call(seed=1 + rank, n_dots=args.dots, n_sources=None):
@@ -148,7 +149,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -158,11 +159,11 @@ def main():
         march_ms += st.march_ms
         iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -215,7 +216,7 @@ def main():
         print(json.dumps(out), flush=True)
     scene.free()
     volume.free()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -22,6 +22,6 @@ def reduce_image(image, dst: int = 0):
     """Sum every rank's private image onto rank `dst` (in place).  `image` is a torch tensor
     (cuda -> RCCL ncclReduce, cpu -> gloo).  No-op without an initialised process group."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
     return image
