@@ -186,7 +186,7 @@ def piv_scene(n_particles: int = 100, rays_per_source: int = 10000, mie: bool = 
                  ray_tracing_algorithm=ray_tracing_algorithm if density_grad_filename else 0, **kw)
 
 
-def config(name: str, workdir: Optional[str] = None, scale: float = 1.0) -> RayTracingCall:
+def config(name: str, workdir: Optional[str] = None, scale: float = 1.0, volume_n: Optional[int] = None) -> RayTracingCall:
     """BASELINE.json configs by name ('C0','C2','C3','C4','C5'); `scale` shrinks ray counts and
     (for volumes) the grid so tests can run the same scene small."""
     name = name.upper()
@@ -198,6 +198,8 @@ def config(name: str, workdir: Optional[str] = None, scale: float = 1.0) -> RayT
         assert workdir is not None, "volume configs need a directory for the NRRD file"
         n = {"C3": 256, "C4": 512, "C5": 256}[name]
         n = max(16, int(round(n * min(1.0, scale ** (1 / 3))))) if scale < 1 else n
+        if volume_n is not None:        # e.g. one GPU's share of C4: fewer sources, full-size grid
+            n = int(volume_n)
         path = os.path.join(workdir, f"bos_{n}.nrrd")
         if not os.path.exists(path):
             rho, sp, org = bos_volume(n)
