@@ -34,6 +34,9 @@ namespace photon {
 #ifndef PHOTON_COOP_GROUPS
 #define PHOTON_COOP_GROUPS 4
 #endif
+#ifndef PHOTON_TILE_REUSE
+#define PHOTON_TILE_REUSE 1
+#endif
 #ifndef PHOTON_INTERIOR_FAST
 #define PHOTON_INTERIOR_FAST 0      // measured: the scalar interior test + second code path costs 2.5 % (88.0 vs 90.1 ms)
 #endif
@@ -79,8 +82,11 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 
 // Must be called by ALL 64 lanes of the wave (wave-uniform control flow); `need` says whether this
 // lane wants a sample.  blk = this wave's 64-texel LDS tile.
+// tile_key (wave-uniform, kept by the caller across samples) names the block currently parked in
+// the tile: consecutive samples of a ray advance by half a texel, so about every other sample finds
+// its block already there and skips the fetch.
 __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
-                                               float x, float y, float z) {
+                                               float x, float y, float z, int &tile_key) {
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
     const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
     float wx[4], wy[4], wz[4];
@@ -103,18 +109,23 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                   ck = __builtin_amdgcn_readlane(bk, leader);
         // one coalesced-ish load instruction for the whole block: 16 rows of 64 contiguous bytes.
         // Interior blocks (the common case; a scalar test) need no per-texel clamping.
-        unsigned idx;
-        if (PHOTON_INTERIOR_FAST && ci >= 1 && ci + 2 < v.nx && cj >= 1 && cj + 2 < v.ny && ck >= 1 && ck + 2 < v.nz) {
-            idx = (unsigned)((ck * v.ny + cj) * v.nx + ci + lane_off);
-        } else {
-            const int tx = clampi(ci - 1 + ta, 0, v.nx - 1), ty = clampi(cj - 1 + tb, 0, v.ny - 1),
-                      tz = clampi(ck - 1 + tc, 0, v.nz - 1);
-            idx = (unsigned)((tz * v.ny + ty) * v.nx + tx);
+        // block id: base texels lie in [-1, n) per axis, so (c+1) fits n+1 values per axis
+        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
+        if (!PHOTON_TILE_REUSE || key != tile_key) {            // wave-uniform (SALU compare)
+            unsigned idx;
+            if (PHOTON_INTERIOR_FAST && ci >= 1 && ci + 2 < v.nx && cj >= 1 && cj + 2 < v.ny && ck >= 1 && ck + 2 < v.nz) {
+                idx = (unsigned)((ck * v.ny + cj) * v.nx + ci + lane_off);
+            } else {
+                const int tx = clampi(ci - 1 + ta, 0, v.nx - 1), ty = clampi(cj - 1 + tb, 0, v.ny - 1),
+                          tz = clampi(ck - 1 + tc, 0, v.nz - 1);
+                idx = (unsigned)((tz * v.ny + ty) * v.nx + tx);
+            }
+            const f4 t = ldtexel(tex + idx);                    // < 2^31 texels (checked on the host)
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+            __builtin_amdgcn_wave_barrier();
+            tile_key = key;
         }
-        const f4 t = ldtexel(tex + idx);                        // < 2^31 texels (checked on the host)
-        __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
-        __builtin_amdgcn_wave_barrier();
         if (!done && bi == ci && bj == cj && bk == ck) {
             acc = cubic_taps_lds(blk, wx, wy, wz);
             done = true;
@@ -207,9 +218,9 @@ __device__ __forceinline__ bool inside_box_u(f3 p, const MarchU &u, f3 l) {
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
 template <int INTERP>
 __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need, f3 lookup,
-                                          const f4 &val_prev, MarchCount &mc) {
+                                          const f4 &val_prev, MarchCount &mc, int &tile_key) {
     f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z)
-                         : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z);
+                         : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, tile_key);
     if (need) mc.samples++;
     if (INTERP == 1) {
         const float ambient = 1.000277;
@@ -235,7 +246,7 @@ template <int INTERP>
 __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
                                          const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc) {
     const MarchU u = make_march_consts(v, scale);
-    int loop_ctr = 0, spins = 0;
+    int loop_ctr = 0, spins = 0, tile_key = -1;
     f4 val_prev = f4{0, 0, 0, 0};
     f3 T_n = rdir, A = mk3(0, 0, 0), B = mk3(0, 0, 0), spos = rpos;     // only meaningful while `go`
     float delta_t = 0.f, current_n = 1.f;
@@ -258,7 +269,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
                 }
             }
         }
-        f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         bool go = false;                                        // lane continues to samples B and C
         if (need) {
             if (INTERP == 2 && val.w < u.data_min) {            // .h:1220-1227
@@ -283,7 +294,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1094-1101
             else need = true;
         }
-        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         if (need) {
             val.w += 1;
             B = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
@@ -297,7 +308,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1135-1141
             else need = true;
         }
-        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         if (need) {
             val.w += 1;
             const f3 C = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
@@ -316,7 +327,7 @@ template <int INTERP>
 __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
                                            const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc) {
     const MarchU u = make_march_consts(v, scale);
-    int loop_ctr = 0, spins = 0;
+    int loop_ctr = 0, spins = 0, tile_key = -1;
     f4 val_prev = f4{0, 0, 0, 0};
     while (__ballot(active) != 0) {
         bool need = false;
@@ -336,7 +347,7 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
                 }
             }
         }
-        const f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc);
+        const f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         if (need) {
             if (INTERP == 1) {
                 const float current_n = 1 + val.w;

@@ -490,7 +490,7 @@ int photon_volume_from_density(const float *rho, int nx, int ny, int nz, const d
     const double xmax = xmin + (nx - 1) * spacing[0], ymax = ymin + (ny - 1) * spacing[1];
     const double zmax = zmin + (nz - 1) * spacing[2];
     if (nz > 1024) nz = 1024;
-    if ((unsigned long long)nx * ny * nz >= (1ull << 31)) {
+    if ((unsigned long long)(nx + 1) * (ny + 1) * (nz + 1) >= (1ull << 31)) {
         fprintf(stderr, "photon: volume of %d x %d x %d texels exceeds the 2^31-texel limit of the samplers\n", nx, ny, nz);
         return 1;
     }
