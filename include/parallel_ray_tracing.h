@@ -127,6 +127,8 @@ typedef struct camera_design_t {
  *   PHOTON_INTERP=linear|cubic   volume sampler (default linear = the reference's
  *                                hard-coded interpolation_scheme 1, .cu:3330)
  *   PHOTON_VERBOSE=1             progress / timing on stdout
+ *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
+ *                                reference seeds cuRAND with time(NULL); default 0x5eed)
  */
 void start_ray_tracing(float lens_pitch, float image_distance,
                        scattering_data_t *scattering_data_p, char *scattering_type_str,
@@ -215,6 +217,13 @@ int photon_scene_create(float lens_pitch, float image_distance,
                         const camera_design_t *camera_design_p, float ray_cone_pitch_ratio,
                         photon_scene_t **out);
 void photon_scene_free(photon_scene_t *scene);
+
+/* Noise hooks of start_ray_tracing (its add_pos_noise / pos_noise_std / add_ngrad_noise /
+ * ngrad_noise_std arguments, parallel_ray_tracing.cu:3405-3445): Gaussian jitter of the sensor hit
+ * (sigma in pixels) and of dn/dx, dn/dy in the Euler march.  Counter-based generator keyed by
+ * `seed` (include/photon_philox.h); off by default. */
+int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_noise_std, int add_ngrad_noise,
+                           float ngrad_noise_std, uint64_t seed);
 
 /* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.

@@ -93,6 +93,14 @@ class Oracle:
     def num_threads(self) -> int:
         return int(self.lib.oracle_num_threads())
 
+    def set_noise_seed(self, seed: int):
+        self.lib.oracle_set_noise_seed(ctypes.c_uint64(int(seed)))
+
+    def normal2(self, seed: int, n: int, draw: int = 0, stream: int = 1):
+        out = np.empty((n, 2), np.float32)
+        self.lib.oracle_normal2(ctypes.c_uint64(int(seed)), int(n), ctypes.c_uint32(draw), ctypes.c_uint32(stream), _p(out))
+        return out
+
     def set_num_threads(self, n: int):
         self.lib.oracle_set_num_threads(int(n))
 

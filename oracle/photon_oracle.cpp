@@ -27,7 +27,8 @@
 //   * loops that can spin forever in the reference (ray never enters the box) are capped;
 //   * sensor accumulation is summed in double per pixel (order-free expectation of the
 //     reference's float atomicAdd in arbitrary order) and rounded to float once;
-//   * cuRAND noise hooks (time(NULL)-seeded in the reference) are not reproduced.
+//   * the noise hooks draw from a seeded counter-based generator (include/photon_philox.h)
+//     instead of time(NULL)-seeded cuRAND states: same hooks, reproducible numbers.
 //
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp, no fast-math).
 
@@ -43,6 +44,7 @@
 
 #include "../include/parallel_ray_tracing.h"
 #include "../include/photon_det_math.h"   // bit-reproducible atan/tan/sin/cos/acos (see its header)
+#include "../include/photon_philox.h"     // counter-based N(0,1) for the optional noise hooks
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -418,6 +420,13 @@ const int SPIN_MAX = 1 << 20;           // our cap on the reference's uncounted 
 
 struct MarchCount { int iterations = 0; int samples = 0; };
 
+struct Noise {                      // the four noise arguments of start_ray_tracing + our seed
+    bool add_pos = false, add_ngrad = false;
+    float pos_std = 0.f, ngrad_std = 0.f;
+    uint64_t seed = 0;
+};
+uint64_t g_noise_seed = 0;          // oracle_set_noise_seed()
+
 // The "val.w < data_min" repair used by the linear branches (.h:834-845, 1056-1065 ...)
 inline f4 fetch_linear(const Volume &v, f3 l, const f4 &prev, float ambient, MarchCount &mc) {
     f4 val = tex3d_linear(v, v.data, l.x, l.y, l.z);
@@ -535,7 +544,7 @@ void rk4(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
 }
 
 // euler, trace_rays_through_density_gradients.h:743-950 (noise hook omitted)
-void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
+void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc, const Noise &nz, uint64_t ray_id) {
     const float ambient = 1.000277;
     int loop_ctr = 0, spins = 0;
     f3 pos, dir, lookup, normal;
@@ -554,6 +563,12 @@ void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
             }
             val = fetch_linear(v, lookup, val_prev, ambient, mc);       // :830-845
             const float current_n = 1 + val.w;
+            if (nz.add_ngrad) {                                         // :853-863
+                float n0, n1;
+                photon_normal2(nz.seed, ray_id, (uint32_t)loop_ctr, PHOTON_STREAM_NGRAD_NOISE, &n0, &n1);
+                val.x += n0 * nz.ngrad_std;
+                val.y += n1 * nz.ngrad_std;
+            }
             normal = mk3(val.x, val.y, val.z);
             dir = dir + v.step_size * normal;                           // :869 (not renormalised)
             pos = pos + v.step_size / current_n * dir;                  // :875
@@ -590,7 +605,8 @@ void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
 }
 
 // trace_rays_through_density_gradients, .h:1455-1544
-void trace_volume(f3 &pos_io, f3 &dir_io, const Volume &v, int algorithm, MarchCount &mc) {
+void trace_volume(f3 &pos_io, f3 &dir_io, const Volume &v, int algorithm, MarchCount &mc, const Noise &nz = Noise(),
+                  uint64_t ray_id = 0) {
     const f3 mn = v.min_bound, mx = v.max_bound;
     const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
     f3 pos = pos_io;
@@ -601,7 +617,7 @@ void trace_volume(f3 &pos_io, f3 &dir_io, const Volume &v, int algorithm, MarchC
     }
     pos_io = pos;
     switch (algorithm) {
-        case 1: euler(pos_io, dir_io, v, scale, mc); break;
+        case 1: euler(pos_io, dir_io, v, scale, mc, nz, ray_id); break;
         case 2: rk4(pos_io, dir_io, v, scale, mc); break;
         default: break;
     }
@@ -835,9 +851,18 @@ inline float sensor_time(f3 src, f3 dir, float a, float b, float c, float d) {
 }
 
 // intersect_sensor_02, parallel_ray_tracing.cu:1383-1543.  Returns final position (NaN = lost).
-f3 sensor_diffraction(Image &img, const Ray &ray, const camera_design_t &cam) {
+inline void add_position_noise(f3 &hit, const camera_design_t &cam, const Noise &nz, uint64_t ray_id) {
+    if (!nz.add_pos) return;                                            // .cu:1424-1434
+    float n0, n1;
+    photon_normal2(nz.seed, ray_id, 0, PHOTON_STREAM_POS_NOISE, &n0, &n1);
+    hit.x += n0 * nz.pos_std * cam.pixel_pitch;
+    hit.y += n1 * nz.pos_std * cam.pixel_pitch;
+}
+
+f3 sensor_diffraction(Image &img, const Ray &ray, const camera_design_t &cam, const Noise &nz, uint64_t ray_id) {
     const float t = sensor_time(ray.pos, ray.dir, 0.0f, 0.0f, 1.0f, -cam.z_sensor);
-    const f3 hit = ray.pos + ray.dir * t;
+    f3 hit = ray.pos + ray.dir * t;
+    add_position_noise(hit, cam, nz, ray_id);
     const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
     const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
     const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;     // x flipped (:1446)
@@ -850,7 +875,7 @@ f3 sensor_diffraction(Image &img, const Ray &ray, const camera_design_t &cam) {
 
 // create_apparent_image, parallel_ray_tracing.cu:1545-1733
 f3 apparent_image(Image &img, const Ray &ray, const camera_design_t &cam, float z_object, float z_offset,
-                  const element_data_t &e) {
+                  const element_data_t &e, const Noise &nz, uint64_t ray_id) {
     const f3 dir = -ray.dir;
     const float t = sensor_time(ray.pos, dir, 0.0f, 0.0f, -1.0f, z_object);
     f3 hit = ray.pos + dir * t;
@@ -858,6 +883,7 @@ f3 apparent_image(Image &img, const Ray &ray, const camera_design_t &cam, float 
     const float M = focal / (z_object - z_offset - focal);
     hit.x = -hit.x * M;
     hit.y = -hit.y * M;
+    add_position_noise(hit, cam, nz, ray_id);                           // .cu:1607-1616
     const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
     const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
     const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;
@@ -869,9 +895,10 @@ f3 apparent_image(Image &img, const Ray &ray, const camera_design_t &cam, float 
 }
 
 // intersect_sensor + the 4-pixel splat loop, parallel_ray_tracing.cu:1735-1895, :2199-2234
-f3 sensor_bilinear(Image &img, const Ray &ray, const camera_design_t &cam) {
+f3 sensor_bilinear(Image &img, const Ray &ray, const camera_design_t &cam, const Noise &nz, uint64_t ray_id) {
     const float t = sensor_time(ray.pos, ray.dir, 0.0f, 0.0f, 1.0f, -cam.z_sensor);
-    const f3 hit = ray.pos + ray.dir * t;
+    f3 hit = ray.pos + ray.dir * t;
+    add_position_noise(hit, cam, nz, ray_id);                           // .cu:1773-1783
     const f3 dir = ray.dir;
     const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
     const double cos4 = photon_det_cosf(alpha) * photon_det_cosf(alpha) * photon_det_cosf(alpha) * photon_det_cosf(alpha);
@@ -923,6 +950,7 @@ struct Scene {
     std::vector<int> sys_index;
     camera_design_t cam;
     std::vector<float> r1, r2;
+    Noise noise;
 };
 
 struct RayOut { f3 pos, dir; };     // what the reference dumps for one ray
@@ -935,6 +963,7 @@ void trace_one(const Scene &sc, const Volume *vol, int algorithm, int64_t source
     Ray ray = generate_ray(sc.lens_pitch, sc.image_distance, sc.sd, sc.scattering_type, s, sc.rays_per_source,
                            sc.beam_wavelength, sc.f_number, sc.r1[local_ray], sc.r2[local_ray], sc.ratio);
     const camera_design_t &cam = sc.cam;
+    const uint64_t ray_id = (uint64_t)source * (uint64_t)sc.rays_per_source + (uint64_t)local_ray;
     if (vol) {                                                          // :2033-2131
         f3 p = ray.pos, d = ray.dir;
         p.z = (float)(p.z - (sc.ls.z_offset + 750e3));
@@ -945,7 +974,7 @@ void trace_one(const Scene &sc, const Volume *vol, int algorithm, int64_t source
             pv[i] = dot(row, p); dv[i] = dot(row, d);
         }
         p = mk3(pv[0], pv[1], pv[2]); d = mk3(dv[0], dv[1], dv[2]);
-        trace_volume(p, d, *vol, algorithm, mc);
+        trace_volume(p, d, *vol, algorithm, mc, sc.noise, ray_id);
         for (int i = 0; i < 3; i++) {
             const f3 row = mk3(cam.rotation_matrix[i * 3], cam.rotation_matrix[i * 3 + 1], cam.rotation_matrix[i * 3 + 2]);
             pv[i] = dot(row, p); dv[i] = dot(row, d);
@@ -959,7 +988,7 @@ void trace_one(const Scene &sc, const Volume *vol, int algorithm, int64_t source
     if (dump) dump->dir = ray.dir;                                      // :2136-2141
     if (sc.elems[0].element_type == 'n') {                              // :2143-2158
         const float z_obj = sc.ls.object_distance + sc.ls.z_offset;
-        const f3 fin = apparent_image(img, ray, cam, z_obj, sc.ls.z_offset, sc.elems[0]);
+        const f3 fin = apparent_image(img, ray, cam, z_obj, sc.ls.z_offset, sc.elems[0], sc.noise, ray_id);
         if (dump) dump->pos = fin;
         if (!std::isnan(fin.x)) on_sensor++;
         return;
@@ -969,11 +998,11 @@ void trace_one(const Scene &sc, const Volume *vol, int algorithm, int64_t source
                          sc.num_elements, ray);
     if (isnan3(ray.dir) || isnan3(ray.pos)) return;                     // :2172-2176
     if (cam.implement_diffraction) {
-        const f3 fin = sensor_diffraction(img, ray, cam);
+        const f3 fin = sensor_diffraction(img, ray, cam, sc.noise, ray_id);
         if (dump) dump->pos = fin;
         if (!std::isnan(fin.x)) on_sensor++;
     } else {
-        const f3 fin = sensor_bilinear(img, ray, cam);
+        const f3 fin = sensor_bilinear(img, ray, cam, sc.noise, ray_id);
         if (std::isnan(fin.x) || std::isnan(fin.y)) return;             // :2196
         if (dump) dump->pos = fin;
         on_sensor++;
@@ -1108,6 +1137,9 @@ void oracle_start_ray_tracing(float lens_pitch, float image_distance, scattering
                 lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
                 element_data_p, element_plane_parameters, element_system_index, camera_design_p,
                 ray_cone_pitch_ratio);
+    sc.noise.add_pos = add_pos_noise; sc.noise.pos_std = pos_noise_std;
+    sc.noise.add_ngrad = add_ngrad_noise; sc.noise.ngrad_std = ngrad_noise_std;
+    sc.noise.seed = g_noise_seed;
     Volume vol;
     const Volume *volp = nullptr;
     if (simulate_density_gradients) {
@@ -1142,6 +1174,9 @@ void oracle_render_with_volume(float lens_pitch, float image_distance, scatterin
                 lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
                 element_data_p, element_plane_parameters, element_system_index, camera_design_p,
                 ray_cone_pitch_ratio);
+    sc.noise.add_pos = add_pos_noise; sc.noise.pos_std = pos_noise_std;
+    sc.noise.add_ngrad = add_ngrad_noise; sc.noise.ngrad_std = ngrad_noise_std;
+    sc.noise.seed = g_noise_seed;
     render_core(sc, simulate_density_gradients ? static_cast<const Volume *>(volume) : nullptr, image_array,
                 save_lightrays, lightray_position_save_path, lightray_direction_save_path, num_lightrays_save,
                 ray_tracing_algorithm, stats);
@@ -1257,6 +1292,13 @@ void oracle_det_eval(int fn, int n, const double *x, double *y) {
             default: y[i] = 0; break;
         }
     }
+}
+
+void oracle_set_noise_seed(uint64_t seed) { g_noise_seed = seed; }
+
+// include/photon_philox.h on the host: n pairs of N(0,1) for rays 0..n-1 (tests)
+void oracle_normal2(uint64_t seed, int n, uint32_t draw, uint32_t stream, float *out) {
+    for (int i = 0; i < n; i++) photon_normal2(seed, (uint64_t)i, draw, stream, &out[2 * i], &out[2 * i + 1]);
 }
 
 void oracle_set_num_threads(int n) {

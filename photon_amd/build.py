@@ -22,6 +22,7 @@ SOURCES = [os.path.join(CSRC, "photon_core.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp", "device_volume_coop.hpp", "device_optics.hpp")] + [
     os.path.join(ROOT, "include", "parallel_ray_tracing.h"),
     os.path.join(ROOT, "include", "photon_det_math.h"),
+    os.path.join(ROOT, "include", "photon_philox.h"),
 ]
 
 # -ffp-contract=off: fused multiply-adds only where the source says fmaf()/fma() -- the rounding

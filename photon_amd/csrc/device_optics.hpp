@@ -11,11 +11,20 @@
 #pragma once
 #include "../../include/parallel_ray_tracing.h"
 #include "../../include/photon_det_math.h"
+#include "../../include/photon_philox.h"
 #include "device_vec.hpp"
 
 namespace photon {
 
 constexpr int kMaxElements = 5;         // MAX_CURRENT_ELEMENTS (.cu:38)
+
+// the four noise arguments of start_ray_tracing + the seed (reference: cuRAND states seeded with
+// time(NULL), .cu:3405-3445; here Philox keyed by PHOTON_NOISE_SEED, include/photon_philox.h)
+struct NoiseDev {
+    int add_pos, add_ngrad;
+    float pos_std, ngrad_std;
+    unsigned long long seed;
+};
 
 // Everything start_ray_tracing uploads before its launch loop (.cu:3132-3314), by value.
 struct SceneDev {
@@ -39,6 +48,7 @@ struct SceneDev {
     float planes[kMaxElements][4];
     int sys_index[kMaxElements];
     camera_design_t cam;
+    NoiseDev noise;
 };
 
 struct Ray {                            // light_ray_data_t
@@ -388,10 +398,22 @@ __device__ __forceinline__ f3 sensor_hit(const Ray &ray, float a, float b, float
     return ray.pos + dir * t;
 }
 
+// Gaussian position noise on the sensor hit, sigma in pixels (.cu:1424-1434, 1607-1616, 1773-1783)
+__device__ __forceinline__ void add_position_noise(f3 &hit, const camera_design_t &cam, const NoiseDev &nz,
+                                                   unsigned long long ray_id) {
+    if (!nz.add_pos) return;
+    float n0, n1;
+    photon_normal2(nz.seed, ray_id, 0, PHOTON_STREAM_POS_NOISE, &n0, &n1);
+    hit.x += n0 * nz.pos_std * cam.pixel_pitch;
+    hit.y += n1 * nz.pos_std * cam.pixel_pitch;
+}
+
 // intersect_sensor_02 (.cu:1383-1543): sensor hit, x axis flipped; fills the splat request.
 // Returns the final position (NaN = outside the sensor, no splat).
-__device__ __forceinline__ f3 sensor_diffraction(const Ray &ray, const camera_design_t &cam, SplatReq &req) {
-    const f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
+__device__ __forceinline__ f3 sensor_diffraction(const Ray &ray, const camera_design_t &cam, SplatReq &req,
+                                                 const NoiseDev &nz, unsigned long long ray_id) {
+    f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
+    add_position_noise(hit, cam, nz, ray_id);
     const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
     const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
     const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;
@@ -404,13 +426,15 @@ __device__ __forceinline__ f3 sensor_diffraction(const Ray &ray, const camera_de
 // create_apparent_image (.cu:1545-1733): back-project to the object plane, scale by the
 // thin-lens magnification, splat with render_fraction 1.
 __device__ __forceinline__ f3 apparent_image(const Ray &ray, const camera_design_t &cam, float z_object, float z_offset,
-                                             const element_data_t &e, SplatReq &req) {
+                                             const element_data_t &e, SplatReq &req, const NoiseDev &nz,
+                                             unsigned long long ray_id) {
     const f3 dir = -ray.dir;
     f3 hit = sensor_hit(ray, 0.0f, 0.0f, -1.0f, z_object, dir);
     const float focal = e.element_properties.thin_lens_focal_length;
     const float M = focal / (z_object - z_offset - focal);
     hit.x = -hit.x * M;
     hit.y = -hit.y * M;
+    add_position_noise(hit, cam, nz, ray_id);
     const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
     const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
     const float d_x = cam.x_pixel_number - 1 - (hit.x - p1x) / cam.pixel_pitch;
@@ -421,8 +445,10 @@ __device__ __forceinline__ f3 apparent_image(const Ray &ray, const camera_design
 }
 
 // intersect_sensor + 4-pixel area-weighted splat (.cu:1735-1895, :2199-2234)
-__device__ __forceinline__ f3 sensor_bilinear(double *image, const Ray &ray, const camera_design_t &cam, int &taps) {
-    const f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
+__device__ __forceinline__ f3 sensor_bilinear(double *image, const Ray &ray, const camera_design_t &cam, int &taps,
+                                              const NoiseDev &nz, unsigned long long ray_id) {
+    f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
+    add_position_noise(hit, cam, nz, ray_id);
     const f3 dir = ray.dir;
     const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
     const float ca = photon_det_cosf(alpha);

@@ -23,6 +23,7 @@
 // Every path evaluates the same fmaf chain in the same order: results are bit-identical to the
 // per-lane samplers in device_volume.hpp and to the CPU oracle.
 #pragma once
+#include "../../include/photon_philox.h"
 #include "device_volume.hpp"
 
 namespace photon {
@@ -323,9 +324,13 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
 
 // Wave-synchronous Euler integrator (reference: .h:743-950, noise hook not built): one
 // cooperative sample per trip.  Per-ray operation order is that of euler<> in device_volume.hpp.
+// Gradient noise of the Euler integrator (.h:853-863): N(0,1)*sigma added to dn/dx, dn/dy.
+struct GradNoise { int on; float std; unsigned long long seed, ray_id; };
+
 template <int INTERP>
 __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
-                                           const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc) {
+                                           const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc,
+                                           const GradNoise &gn) {
     const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0, tile_key = -1;
     f4 val_prev = f4{0, 0, 0, 0};
@@ -347,10 +352,16 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
                 }
             }
         }
-        const f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         if (need) {
             if (INTERP == 1) {
                 const float current_n = 1 + val.w;
+                if (gn.on) {
+                    float n0, n1;
+                    photon_normal2(gn.seed, gn.ray_id, (unsigned)loop_ctr, PHOTON_STREAM_NGRAD_NOISE, &n0, &n1);
+                    val.x += n0 * gn.std;
+                    val.y += n1 * gn.std;
+                }
                 rdir = rdir + u.step * mk3(val.x, val.y, val.z);       // .h:869 (not renormalised)
                 rpos = rpos + u.step / current_n * rdir;                // .h:875
                 val_prev = val;
@@ -374,7 +385,8 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
 // carries a ray at all (tail lanes of the last workgroup do not).
 template <int ALGO, int INTERP>
 __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &dir_io, const VolumeDev &v,
-                                                  const f4 *__restrict__ tex, f4 *blk, MarchCount &mc) {
+                                                  const f4 *__restrict__ tex, f4 *blk, MarchCount &mc,
+                                                  const GradNoise &gn) {
     const f3 mn = v.min_bound, mx = v.max_bound;
     const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
     bool active = has_ray;
@@ -386,7 +398,7 @@ __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &
         }
         if (active) pos_io = pos;
     }
-    if (ALGO == 1) euler_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc);
+    if (ALGO == 1) euler_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn);
     else rk4_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc);
 }
 

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
         d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     }
     MarchCount mc{0, 0};
-    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc);
+    const GradNoise no_noise{0, 0.f, 0ull, 0ull};
+    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise);
     if (has_ray) {
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
         dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #endif
 template <int ALGO, int INTERP>
 __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
-                                                       RayStateDev st, unsigned long long *__restrict__ counters) {
+                                                       RayStateDev st, unsigned long long *__restrict__ counters,
+                                                       NoiseDev noise, unsigned long long ray_base) {
     __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDe
         p = mk3(st.px[r], st.py[r], st.pz[r]);
         d = mk3(st.dx[r], st.dy[r], st.dz[r]);
     }
-    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc);   // all 64 lanes
+    const GradNoise gn{noise.add_ngrad, noise.ngrad_std, noise.seed, ray_base + r};
+    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn);   // all 64 lanes
     if (has_ray) {
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
             ray = generate_ray(sc, (int)(src_begin + r / rps), (int)(r % rps));
         }
         const bool dumping = dump.final_pos != nullptr && r < (unsigned)dump.num_save;
+        const unsigned long long ray_id = (unsigned long long)src_begin * (unsigned)sc.rays_per_source + r;
         f3 fin = nan3();
         bool have_fin = false;
         if (alive) {
@@ -319,18 +323,18 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
             }
             if (sc.elems[0].element_type == 'n') {                      // .cu:2143-2158
                 const float z_obj = sc.object_distance + sc.z_offset;
-                fin = apparent_image(ray, sc.cam, z_obj, sc.z_offset, sc.elems[0], req);
+                fin = apparent_image(ray, sc.cam, z_obj, sc.z_offset, sc.elems[0], req, sc.noise, ray_id);
                 have_fin = true;
                 on_sensor = !isnan(fin.x);
             } else {
                 ray = optical_system(sc, ray);
                 if (!(isnan3(ray.dir) || isnan3(ray.pos))) {            // .cu:2172-2176
                     if (sc.cam.implement_diffraction) {
-                        fin = sensor_diffraction(ray, sc.cam, req);
+                        fin = sensor_diffraction(ray, sc.cam, req, sc.noise, ray_id);
                         have_fin = true;
                         on_sensor = !isnan(fin.x);
                     } else {
-                        fin = sensor_bilinear(image, ray, sc.cam, taps);
+                        fin = sensor_bilinear(image, ray, sc.cam, taps, sc.noise, ray_id);
                         have_fin = !(isnan(fin.x) || isnan(fin.y));     // .cu:2196
                         on_sensor = have_fin;
                     }
@@ -692,6 +696,7 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
         d.sys_index[k] = element_system_index[k];
     }
     d.cam = *cam;
+    d.noise = NoiseDev{0, 0, 0.f, 0.f, 0ull};
     if (cam->x_pixel_number < 1 || cam->y_pixel_number < 1) {
         fprintf(stderr, "photon: sensor needs at least one pixel\n");
         return bail(1);
@@ -705,6 +710,14 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
         if (e != hipSuccess) { fprintf(stderr, "photon: hipEventCreate failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     }
     *out = s;
+    return 0;
+}
+
+int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_noise_std, int add_ngrad_noise,
+                           float ngrad_noise_std, uint64_t seed) {
+    if (!scene) return 1;
+    scene->dev.noise = NoiseDev{add_pos_noise ? 1 : 0, add_ngrad_noise ? 1 : 0, pos_noise_std, ngrad_noise_std,
+                                (unsigned long long)seed};
     return 0;
 }
 
@@ -757,10 +770,11 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         if (timed) PH_CHECK(hipEventRecord(s->ev[1], stream));
         const int interp = vol->dev.interpolation;
         const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
-        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
-        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
-        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
-        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters);
+        const unsigned long long ray_base = (unsigned long long)src_begin * (unsigned)s->dev.rays_per_source;
+        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
+        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
+        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
+        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
         PH_CHECK(hipGetLastError());
         if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
         hipLaunchKernelGGL((sensor_kernel<true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
@@ -894,14 +908,12 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                                   float pos_noise_std, bool add_ngrad_noise, float ngrad_noise_std,
                                   float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
                                   int num_intermediate_positions_save) {
-    (void)pos_noise_std; (void)ngrad_noise_std; (void)num_intermediate_positions_save;
+    (void)num_intermediate_positions_save;
     const auto t0 = std::chrono::steady_clock::now();
     if (!image_array || !camera_design_p || !lightfield_source_p) {
         fprintf(stderr, "photon: start_ray_tracing: null argument; image left untouched\n");
         return;
     }
-    if (simulate_density_gradients && (add_pos_noise || add_ngrad_noise))
-        fprintf(stderr, "photon: warning: position / gradient noise hooks are not built in this version; ignored\n");
     if (save_intermediate_ray_data)
         fprintf(stderr, "photon: warning: intermediate ray dumps are not built in this version; ignored\n");
     if (simulate_density_gradients && ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) {
@@ -924,6 +936,13 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                             camera_design_p, ray_cone_pitch_ratio, &scene)) {
         fprintf(stderr, "photon: scene upload failed; image left untouched\n");
         return;
+    }
+    {   // noise hooks: same switches as the reference; seed from the environment instead of time(NULL)
+        const char *e = getenv("PHOTON_NOISE_SEED");
+        const uint64_t seed = e ? strtoull(e, nullptr, 0) : 0x5eedULL;
+        // gradient noise only exists inside the volume march (Euler, .h:853-863)
+        photon_scene_set_noise(scene, add_pos_noise, pos_noise_std, simulate_density_gradients && add_ngrad_noise,
+                               ngrad_noise_std, seed);
     }
     photon_volume *vol = nullptr;
     if (simulate_density_gradients) {

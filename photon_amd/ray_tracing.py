@@ -406,6 +406,55 @@ def postprocess_image(I_raw: np.ndarray, pixel_gain: float, pixel_bit_depth: int
     return np.uint16(I)
 
 
+def write_tiff_u16(path: str, image: np.ndarray) -> str:
+    """Minimal baseline TIFF writer (little-endian, one strip, 16-bit grayscale, uncompressed) for the
+    uint16 sensor image -- what the reference writes with its vendored tifffile
+    (run_simulation_02.py:1864, 2052, 2086).  Readable by any TIFF reader."""
+    import struct
+    img = np.ascontiguousarray(image, dtype="<u2")
+    h, w = img.shape
+    data = img.tobytes()
+    entries = [  # (tag, type, count, value)   type 3 = SHORT, 4 = LONG
+        (256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1),
+        (273, 4, 1, 8), (277, 3, 1, 1), (278, 4, 1, h), (279, 4, 1, len(data)), (339, 3, 1, 1),
+    ]
+    ifd_offset = 8 + len(data) + (len(data) & 1)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2sHI", b"II", 42, ifd_offset))
+        f.write(data)
+        if len(data) & 1:
+            f.write(b"\0")
+        f.write(struct.pack("<H", len(entries)))
+        for tag, typ, count, value in entries:
+            f.write(struct.pack("<HHI", tag, typ, count))
+            f.write(struct.pack("<HH", value, 0) if typ == 3 else struct.pack("<I", value))
+        f.write(struct.pack("<I", 0))
+    return path
+
+
+def read_tiff_u16(path: str) -> np.ndarray:
+    """Reader for the files write_tiff_u16 produces (tests)."""
+    import struct
+    with open(path, "rb") as f:
+        buf = f.read()
+    assert buf[:4] == b"II*\0"
+    (ifd,) = struct.unpack_from("<I", buf, 4)
+    (n,) = struct.unpack_from("<H", buf, ifd)
+    tags = {}
+    for i in range(n):
+        tag, typ, count = struct.unpack_from("<HHI", buf, ifd + 2 + 12 * i)
+        tags[tag] = struct.unpack_from("<H" if typ == 3 else "<I", buf, ifd + 2 + 12 * i + 8)[0]
+    w, h, off = tags[256], tags[257], tags[273]
+    return np.frombuffer(buf, dtype="<u2", count=w * h, offset=off).reshape(h, w).copy()
+
+
+def save_images(image_raw: np.ndarray, image_u16: np.ndarray, tif_path: str, raw_path: str):
+    """What the driver does with the two results of a render (run_simulation_02.py:2049-2058):
+    uint16 TIFF + raw float32 dump."""
+    write_tiff_u16(tif_path, image_u16)
+    np.asarray(image_raw, dtype=np.float32).tofile(raw_path)
+
+
 # ----------------------------------------------------------------------------------------------
 # Library loading
 # ----------------------------------------------------------------------------------------------

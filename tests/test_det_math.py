@@ -49,3 +49,22 @@ def test_special_values(oracle):
     a = oracle.det_eval(ATAN, [np.inf, -np.inf, 0.0, np.nan])
     assert a[0] == pytest.approx(np.pi / 2) and a[1] == pytest.approx(-np.pi / 2) and a[2] == 0.0 and np.isnan(a[3])
     assert oracle.det_eval(SIN, [0.0])[0] == 0.0 and oracle.det_eval(COS, [0.0])[0] == 1.0
+
+
+def test_philox_normals_are_standard_normal_and_keyed(oracle):
+    """include/photon_philox.h: N(0,1) pairs addressed by (seed, ray, draw, stream)."""
+    a = oracle.normal2(seed=123, n=400_000)
+    assert abs(a.mean()) < 5e-3 and abs(a.std() - 1.0) < 5e-3
+    assert abs(np.mean(a[:, 0] * a[:, 1])) < 5e-3                      # the two variates are uncorrelated
+    assert abs(np.mean(a ** 4) - 3.0) < 0.05                           # Gaussian kurtosis
+    assert np.array_equal(a, oracle.normal2(seed=123, n=400_000))      # reproducible
+    assert not np.array_equal(a[:1000], oracle.normal2(seed=124, n=1000))
+    assert not np.array_equal(a[:1000], oracle.normal2(seed=123, n=1000, draw=1))
+    assert not np.array_equal(a[:1000], oracle.normal2(seed=123, n=1000, stream=2))
+    # Philox4x32-10 known answer (Random123 kat_vectors: counter 0, key 0)
+    # first word of philox4x32-10(ctr={0,0,0,0}, key={0,0}) = 0x6627e8d5
+    u1 = (0x6627e8d5 + 0.5) / 2 ** 32
+    u2 = (0xe169c58d + 0.5) / 2 ** 32
+    z = oracle.normal2(seed=0, n=1, draw=0, stream=0)[0]
+    r = np.sqrt(-2 * np.log(u1))
+    assert np.allclose(z, [r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)], rtol=1e-6)

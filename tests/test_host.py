@@ -8,7 +8,8 @@ import pytest
 
 from conftest import GOLDEN
 from photon_amd import scenes
-from photon_amd.ray_tracing import postprocess_image, single_lens_camera
+from photon_amd.ray_tracing import (postprocess_image, read_tiff_u16, save_images, single_lens_camera,
+                                    write_tiff_u16)
 from photon_amd.sharding import shard_range
 
 
@@ -77,3 +78,18 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_tiff_and_raw_writers_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    raw = rng.gamma(2.0, 3.0, size=(37, 53)).astype(np.float32)
+    u16 = postprocess_image(raw, 25.0, 10)
+    tif, binf = str(tmp_path / "a.tif"), str(tmp_path / "a.bin")
+    save_images(raw, u16, tif, binf)
+    assert np.array_equal(read_tiff_u16(tif), u16)
+    assert np.array_equal(np.fromfile(binf, np.float32).reshape(raw.shape), raw)
+    # the reference's vendored tifffile is not shipped with the tests; check the header by hand
+    with open(tif, "rb") as f:
+        assert f.read(4) == b"II*\x00"
+    write_tiff_u16(str(tmp_path / "odd.tif"), np.arange(15, dtype=np.uint16).reshape(3, 5))
+    assert np.array_equal(read_tiff_u16(str(tmp_path / "odd.tif")), np.arange(15).reshape(3, 5))

@@ -259,6 +259,38 @@ def test_ray_dumps_bit_exact(photon, oracle, small_volume_file, tmp_path):
     assert np.isfinite(np.fromfile(outs["gpu"][0] / "pos_0000.bin", np.float32)).any()
 
 
+def test_position_noise_hook(photon, oracle, monkeypatch):
+    """add_pos_noise: seeded Gaussian jitter of the sensor hit (reference: time-seeded cuRAND, so
+    only our two implementations can be compared).  Erf and 4-pixel splat paths."""
+    monkeypatch.setenv("PHOTON_NOISE_SEED", "77")
+    oracle.set_noise_seed(77)
+    for call in (scenes.bos_scene(n_dots=6, points_per_dot=20, rays_per_source=100),
+                 scenes.piv_scene(n_particles=60, rays_per_source=400, mie=False, seed=2)):
+        clean = photon.render(call)
+        call.add_pos_noise, call.pos_noise_std = True, 0.5
+        g, o, _ = _render_both(photon, oracle, call)
+        assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+        assert rel_l2(g, clean) > 1e-2                                  # the noise really blurs the image
+    oracle.set_noise_seed(0)
+
+
+def test_gradient_noise_hook(photon, oracle, small_volume_file, monkeypatch):
+    """add_ngrad_noise: Gaussian noise on dn/dx, dn/dy in the Euler march (trilinear branch)."""
+    monkeypatch.setenv("PHOTON_NOISE_SEED", "5")
+    monkeypatch.setenv("PHOTON_INTERP", "linear")
+    oracle.set_noise_seed(5)
+    call = scenes.bos_scene(n_dots=6, points_per_dot=20, rays_per_source=100, density_grad_filename=small_volume_file,
+                            ray_tracing_algorithm=1)
+    clean = photon.render(call)
+    call.add_ngrad_noise, call.ngrad_noise_std = True, 2e-8
+    g = photon.render(call)
+    o, st = oracle.render(call, interpolation=1)
+    assert st.rk_iterations > 0
+    assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+    assert rel_l2(g, clean) > 1e-3
+    oracle.set_noise_seed(0)
+
+
 def test_errors_leave_image_untouched(photon, small_volume_file, capfd):
     call = scenes.bos_scene(n_dots=2, points_per_dot=5, rays_per_source=8, density_grad_filename=small_volume_file)
     img = np.full(call.image_shape, 1.5, np.float32)
