@@ -427,6 +427,13 @@ struct Noise {                      // the four noise arguments of start_ray_tra
 };
 uint64_t g_noise_seed = 0;          // oracle_set_noise_seed()
 
+// Intermediate dumps (save_intermediate_ray_data): one ray's row of `slots` positions / directions.
+// Only the trilinear branches of euler / rk4 record them (.h:784-790, 1004-1008).
+struct InterRec { f3 *pos = nullptr, *dir = nullptr; int slots = 0; };
+inline void record_intermediate(const InterRec *ir, int loop_ctr, const f3 &p, const f3 &d) {
+    if (ir && ir->pos && loop_ctr < ir->slots) { ir->pos[loop_ctr] = p; ir->dir[loop_ctr] = d; }
+}
+
 // The "val.w < data_min" repair used by the linear branches (.h:834-845, 1056-1065 ...)
 inline f4 fetch_linear(const Volume &v, f3 l, const f4 &prev, float ambient, MarchCount &mc) {
     f4 val = tex3d_linear(v, v.data, l.x, l.y, l.z);
@@ -444,7 +451,7 @@ inline f4 fetch_linear(const Volume &v, f3 l, const f4 &prev, float ambient, Mar
 }
 
 // rk4, trace_rays_through_density_gradients.h:952-1291 (Sharma et al. 1982)
-void rk4(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
+void rk4(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc, const InterRec *ir = nullptr) {
     const float ambient = 1.000277;
     int loop_ctr = 0, spins = 0;
     f3 pos, lookup, R_n, T_n, A, B, C, D;
@@ -453,6 +460,7 @@ void rk4(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
     if (v.interpolation == 1) {                                         // :992-1181
         while (true) {
             if (loop_ctr > LOOP_MAX) break;
+            record_intermediate(ir, loop_ctr, rpos, rdir);              // :1004-1008
             pos = rpos;
             lookup = lookup_index(pos, v, scale);
             if (!inside_box(pos, v, lookup) && loop_ctr != 0) break;   // :1021
@@ -544,7 +552,8 @@ void rk4(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
 }
 
 // euler, trace_rays_through_density_gradients.h:743-950 (noise hook omitted)
-void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc, const Noise &nz, uint64_t ray_id) {
+void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc, const Noise &nz, uint64_t ray_id,
+           const InterRec *ir = nullptr) {
     const float ambient = 1.000277;
     int loop_ctr = 0, spins = 0;
     f3 pos, dir, lookup, normal;
@@ -552,6 +561,7 @@ void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc, const 
     if (v.interpolation == 1) {                                         // :770-894
         while (true) {
             if (loop_ctr > LOOP_MAX) break;
+            record_intermediate(ir, loop_ctr, rpos, rdir);              // :784-790
             pos = rpos; dir = rdir;
             lookup = lookup_index(pos, v, scale);
             if (!inside_box(pos, v, lookup) && loop_ctr != 0) break;
@@ -606,7 +616,7 @@ void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc, const 
 
 // trace_rays_through_density_gradients, .h:1455-1544
 void trace_volume(f3 &pos_io, f3 &dir_io, const Volume &v, int algorithm, MarchCount &mc, const Noise &nz = Noise(),
-                  uint64_t ray_id = 0) {
+                  uint64_t ray_id = 0, const InterRec *ir = nullptr) {
     const f3 mn = v.min_bound, mx = v.max_bound;
     const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
     f3 pos = pos_io;
@@ -617,8 +627,8 @@ void trace_volume(f3 &pos_io, f3 &dir_io, const Volume &v, int algorithm, MarchC
     }
     pos_io = pos;
     switch (algorithm) {
-        case 1: euler(pos_io, dir_io, v, scale, mc, nz, ray_id); break;
-        case 2: rk4(pos_io, dir_io, v, scale, mc); break;
+        case 1: euler(pos_io, dir_io, v, scale, mc, nz, ray_id, ir); break;
+        case 2: rk4(pos_io, dir_io, v, scale, mc, ir); break;
         default: break;
     }
 }
@@ -957,7 +967,7 @@ struct RayOut { f3 pos, dir; };     // what the reference dumps for one ray
 
 // Body of the master kernel for one ray, parallel_ray_tracing.cu:1923-2243.
 void trace_one(const Scene &sc, const Volume *vol, int algorithm, int64_t source, int local_ray,
-               Image &img, MarchCount &mc, RayOut *dump, uint64_t &on_sensor) {
+               Image &img, MarchCount &mc, RayOut *dump, uint64_t &on_sensor, const InterRec *ir = nullptr) {
     Source s{sc.ls.x[source], sc.ls.y[source], sc.ls.z[source], sc.ls.radiance[source],
              sc.ls.diameter_index[source]};
     Ray ray = generate_ray(sc.lens_pitch, sc.image_distance, sc.sd, sc.scattering_type, s, sc.rays_per_source,
@@ -974,7 +984,7 @@ void trace_one(const Scene &sc, const Volume *vol, int algorithm, int64_t source
             pv[i] = dot(row, p); dv[i] = dot(row, d);
         }
         p = mk3(pv[0], pv[1], pv[2]); d = mk3(dv[0], dv[1], dv[2]);
-        trace_volume(p, d, *vol, algorithm, mc, sc.noise, ray_id);
+        trace_volume(p, d, *vol, algorithm, mc, sc.noise, ray_id, ir);
         for (int i = 0; i < 3; i++) {
             const f3 row = mk3(cam.rotation_matrix[i * 3], cam.rotation_matrix[i * 3 + 1], cam.rotation_matrix[i * 3 + 2]);
             pv[i] = dot(row, p); dv[i] = dot(row, d);
@@ -1053,7 +1063,8 @@ struct oracle_stats_t {
 // Shared body: the launch loop of parallel_ray_tracing.cu:3366-3675 on the CPU.
 static void render_core(Scene &sc, const Volume *volp, float *image_array, bool save_lightrays,
                         char *lightray_position_save_path, char *lightray_direction_save_path,
-                        int num_lightrays_save, int ray_tracing_algorithm, oracle_stats_t *stats) {
+                        int num_lightrays_save, int ray_tracing_algorithm, oracle_stats_t *stats,
+                        int inter_slots = 0) {
     const int W = sc.cam.x_pixel_number, H = sc.cam.y_pixel_number;
     const int64_t num_particles = sc.ls.num_particles;
     int64_t chunk = sc.ls.source_point_number;                          // .cu:3366-3372
@@ -1070,12 +1081,17 @@ static void render_core(Scene &sc, const Volume *volp, float *image_array, bool 
     for (auto &im : imgs) { im.W = W; im.H = H; im.acc.assign((size_t)W * H, 0.0); }
     std::vector<MarchCount> mcs(nthreads);
     std::vector<uint64_t> on_sensor(nthreads, 0);
-    std::vector<f3> fpos, fdir;
+    std::vector<f3> fpos, fdir, ipos, idir;
+    const bool inter = save_lightrays && volp && inter_slots > 0;      // .cu:3484
     for (int64_t k = 0; k < kmax; k++) {
         const int64_t n_min = k * chunk;
         if (save_lightrays) {
             fpos.assign(num_lightrays_save, mk3(NANF, NANF, NANF));
             fdir.assign(num_lightrays_save, mk3(NANF, NANF, NANF));
+        }
+        if (inter) {                                                    // .cu:3535-3546
+            ipos.assign((size_t)num_lightrays_save * inter_slots, mk3(NANF, NANF, NANF));
+            idir.assign((size_t)num_lightrays_save * inter_slots, mk3(NANF, NANF, NANF));
         }
 #pragma omp parallel for schedule(dynamic, 64)
         for (int64_t gid = 0; gid < num_rays; gid++) {                  // one iteration = one GPU thread
@@ -1089,13 +1105,19 @@ static void render_core(Scene &sc, const Volume *volp, float *image_array, bool 
             if (source >= num_particles) continue;                      // .cu:1967
             RayOut out{mk3(NANF, NANF, NANF), mk3(NANF, NANF, NANF)};
             const bool dump = save_lightrays && gid < num_lightrays_save;
+            InterRec ir;
+            if (inter && dump) ir = InterRec{&ipos[(size_t)gid * inter_slots], &idir[(size_t)gid * inter_slots], inter_slots};
             trace_one(sc, volp, ray_tracing_algorithm, source, lr, imgs[tid], mcs[tid], dump ? &out : nullptr,
-                      on_sensor[tid]);
+                      on_sensor[tid], &ir);
             if (dump) { fpos[gid] = out.pos; fdir[gid] = out.dir; }
         }
         if (save_lightrays) {
             write_dump(lightray_position_save_path, "pos_", (int)k, fpos);
             write_dump(lightray_direction_save_path, "dir_", (int)k, fdir);
+        }
+        if (inter) {                                                    // .cu:3613-3670
+            write_dump(lightray_position_save_path, "intermediate_pos_", (int)k, ipos);
+            write_dump(lightray_direction_save_path, "intermediate_dir_", (int)k, idir);
         }
     }
 #pragma omp parallel for schedule(static)
@@ -1152,7 +1174,8 @@ void oracle_start_ray_tracing(float lens_pitch, float image_distance, scattering
         volp = &vol;
     }
     render_core(sc, volp, image_array, save_lightrays, lightray_position_save_path, lightray_direction_save_path,
-                num_lightrays_save, ray_tracing_algorithm, stats);
+                num_lightrays_save, ray_tracing_algorithm, stats,
+                save_intermediate_ray_data ? num_intermediate_positions_save : 0);
 }
 
 // Same, with a volume built beforehand by oracle_volume_* (NULL = no density gradients): lets the
@@ -1179,7 +1202,7 @@ void oracle_render_with_volume(float lens_pitch, float image_distance, scatterin
     sc.noise.seed = g_noise_seed;
     render_core(sc, simulate_density_gradients ? static_cast<const Volume *>(volume) : nullptr, image_array,
                 save_lightrays, lightray_position_save_path, lightray_direction_save_path, num_lightrays_save,
-                ray_tracing_algorithm, stats);
+                ray_tracing_algorithm, stats, save_intermediate_ray_data ? num_intermediate_positions_save : 0);
 }
 
 void oracle_rand_table(int n, float *r1, float *r2) { rand_table(n, r1, r2); }

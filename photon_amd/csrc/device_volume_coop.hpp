@@ -243,9 +243,23 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
 // reference's `break`); a lane that has to step forward without sampling (the reference's
 // `continue`) sits out the rest of the trip and retries on the next one.  The per-ray operation
 // order is that of rk4<> in device_volume.hpp.
-template <int INTERP>
+// Intermediate ray dumps (save_intermediate_ray_data): position / direction at the start of each
+// of the first `slots` iterations, [ray][slot] float3, world frame.  Like the reference only the
+// trilinear branches record them (.h:784-790, 1004-1008); unlike it the ray index is bounds-checked
+// (the reference indexes a num_lightrays_save-sized buffer with the unchecked thread id).
+struct InterDump { float *pos, *dir; int slots, num_save; unsigned ray; };
+__device__ __forceinline__ void record_intermediate(const InterDump &d, int loop_ctr, f3 p, f3 q) {
+    if (d.pos != nullptr && loop_ctr < d.slots && d.ray < (unsigned)d.num_save) {
+        const size_t o = ((size_t)d.ray * d.slots + loop_ctr) * 3;
+        d.pos[o] = p.x; d.pos[o + 1] = p.y; d.pos[o + 2] = p.z;
+        d.dir[o] = q.x; d.dir[o + 1] = q.y; d.dir[o + 2] = q.z;
+    }
+}
+
+template <int INTERP, bool SAVE>
 __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
-                                         const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc) {
+                                         const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc,
+                                         const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0, tile_key = -1;
     f4 val_prev = f4{0, 0, 0, 0};
@@ -259,6 +273,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             if (loop_ctr > kLoopMax) {
                 active = false;
             } else {
+                if (SAVE && INTERP == 1) record_intermediate(idump, loop_ctr, rpos, rdir);
                 lookup = lookup_index_u(rpos, u);
                 if (!inside_box_u(rpos, u, lookup) && loop_ctr != 0) {
                     active = false;                             // left the volume: done
@@ -327,10 +342,11 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
 // Gradient noise of the Euler integrator (.h:853-863): N(0,1)*sigma added to dn/dx, dn/dy.
 struct GradNoise { int on; float std; unsigned long long seed, ray_id; };
 
-template <int INTERP>
+
+template <int INTERP, bool SAVE>
 __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
                                            const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc,
-                                           const GradNoise &gn) {
+                                           const GradNoise &gn, const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0, tile_key = -1;
     f4 val_prev = f4{0, 0, 0, 0};
@@ -341,6 +357,7 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
             if (loop_ctr > kLoopMax) {
                 active = false;
             } else {
+                if (SAVE && INTERP == 1) record_intermediate(idump, loop_ctr, rpos, rdir);
                 lookup = lookup_index_u(rpos, u);
                 if (!inside_box_u(rpos, u, lookup) && loop_ctr != 0) {
                     active = false;
@@ -383,10 +400,10 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
 
 // trace_rays_through_density_gradients (.h:1455-1544), wave-synchronous.  has_ray = this lane
 // carries a ray at all (tail lanes of the last workgroup do not).
-template <int ALGO, int INTERP>
+template <int ALGO, int INTERP, bool SAVE>
 __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &dir_io, const VolumeDev &v,
                                                   const f4 *__restrict__ tex, f4 *blk, MarchCount &mc,
-                                                  const GradNoise &gn) {
+                                                  const GradNoise &gn, const InterDump &idump) {
     const f3 mn = v.min_bound, mx = v.max_bound;
     const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
     bool active = has_ray;
@@ -398,8 +415,8 @@ __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &
         }
         if (active) pos_io = pos;
     }
-    if (ALGO == 1) euler_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn);
-    else rk4_coop<INTERP>(active, pos_io, dir_io, v, tex, blk, scale, mc);
+    if (ALGO == 1) euler_coop<INTERP, SAVE>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump);
+    else rk4_coop<INTERP, SAVE>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump);
 }
 
 }  // namespace photon

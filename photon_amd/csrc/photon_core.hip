@@ -74,6 +74,9 @@ struct DumpDev {                    // ray dumps (save_lightrays), indexed by ch
     float *final_pos;               // [num_save][3] or nullptr
     float *final_dir;
     int num_save;
+    float *inter_pos;               // [num_save][inter_slots][3] or nullptr (save_intermediate_ray_data)
+    float *inter_dir;
+    int inter_slots;
 };
 
 enum { CNT_ON_SENSOR = 0, CNT_ITER = 1, CNT_SAMPLES = 2, CNT_TAPS = 3, CNT_N = 4 };
@@ -220,7 +223,8 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
     }
     MarchCount mc{0, 0};
     const GradNoise no_noise{0, 0.f, 0ull, 0ull};
-    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise);
+    const InterDump no_dump{nullptr, nullptr, 0, 0, 0u};
+    trace_volume_coop<ALGO, INTERP, false>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
     if (has_ray) {
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
         dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
@@ -259,10 +263,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #ifndef PHOTON_MARCH_WAVES
 #define PHOTON_MARCH_WAVES 4
 #endif
-template <int ALGO, int INTERP>
+template <int ALGO, int INTERP, bool SAVE>
 __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters,
-                                                       NoiseDev noise, unsigned long long ray_base) {
+                                                       NoiseDev noise, unsigned long long ray_base, InterDump idump) {
     __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDe
         d = mk3(st.dx[r], st.dy[r], st.dz[r]);
     }
     const GradNoise gn{noise.add_ngrad, noise.ngrad_std, noise.seed, ray_base + r};
-    trace_volume_coop<ALGO, INTERP>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn);   // all 64 lanes
+    idump.ray = r;                                              // chunk-global ray id, like the final dumps
+    trace_volume_coop<ALGO, INTERP, SAVE>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
     if (has_ray) {
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
@@ -771,10 +776,15 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         const int interp = vol->dev.interpolation;
         const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
         const unsigned long long ray_base = (unsigned long long)src_begin * (unsigned)s->dev.rays_per_source;
-        if (algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_kernel<1, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
-        else if (algorithm == 1) hipLaunchKernelGGL((march_kernel<1, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
-        else if (interp == 1) hipLaunchKernelGGL((march_kernel<2, 1>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
-        else hipLaunchKernelGGL((march_kernel<2, 2>), grid, block, 0, stream, vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base);
+        const InterDump idump{dump.inter_pos, dump.inter_dir, dump.inter_slots, dump.num_save, 0u};
+        const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
+#define PH_MARCH(A, I, S) hipLaunchKernelGGL((march_kernel<A, I, S>), grid, block, 0, stream, vol->dev, tex, n, s->ws, \
+                                             s->d_counters, s->dev.noise, ray_base, idump)
+        if (algorithm == 1 && interp == 1) { if (save) PH_MARCH(1, 1, true); else PH_MARCH(1, 1, false); }
+        else if (algorithm == 1) PH_MARCH(1, 2, false);
+        else if (interp == 1) { if (save) PH_MARCH(2, 1, true); else PH_MARCH(2, 1, false); }
+        else PH_MARCH(2, 2, false);
+#undef PH_MARCH
         PH_CHECK(hipGetLastError());
         if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
         hipLaunchKernelGGL((sensor_kernel<true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
@@ -806,7 +816,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
         PH_CHECK(hipEventRecord(scene->ev[0], stream));
     }
     float march_ms = 0.f;
-    const DumpDev no_dump{nullptr, nullptr, 0};
+    const DumpDev no_dump{nullptr, nullptr, 0, nullptr, nullptr, 0};
     { const int rc = begin_accumulate(scene, stream); if (rc) return rc; }
     for (long long b = src_begin; b < src_end; b += max_sources) {
         const long long e = std::min<long long>(src_end, b + max_sources);
@@ -908,26 +918,25 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                                   float pos_noise_std, bool add_ngrad_noise, float ngrad_noise_std,
                                   float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
                                   int num_intermediate_positions_save) {
-    (void)num_intermediate_positions_save;
     const auto t0 = std::chrono::steady_clock::now();
     if (!image_array || !camera_design_p || !lightfield_source_p) {
         fprintf(stderr, "photon: start_ray_tracing: null argument; image left untouched\n");
         return;
     }
-    if (save_intermediate_ray_data)
-        fprintf(stderr, "photon: warning: intermediate ray dumps are not built in this version; ignored\n");
     if (simulate_density_gradients && ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) {
         fprintf(stderr, "photon: ray_tracing_algorithm %d (rk45 / adams-bashforth) is not built; image left untouched\n",
                 ray_tracing_algorithm);
         return;
     }
     photon_scene *scene = nullptr;
-    float *d_image = nullptr, *d_fpos = nullptr, *d_fdir = nullptr;
+    float *d_image = nullptr, *d_fpos = nullptr, *d_fdir = nullptr, *d_ipos = nullptr, *d_idir = nullptr;
     auto cleanup = [&]() {
         if (scene) photon_scene_free(scene);
         if (d_image) (void)hipFree(d_image);
         if (d_fpos) (void)hipFree(d_fpos);
         if (d_fdir) (void)hipFree(d_fdir);
+        if (d_ipos) (void)hipFree(d_ipos);
+        if (d_idir) (void)hipFree(d_idir);
     };
 #define PH_VOID(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fprintf(stderr, "photon: HIP error %d (%s) at %s:%d; image left untouched\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); cleanup(); return; } } while (0)
     if (photon_scene_create(lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
@@ -971,12 +980,24 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
         PH_VOID(hipMalloc((void **)&d_fpos, nsave * sizeof(float)));
         PH_VOID(hipMalloc((void **)&d_fdir, nsave * sizeof(float)));
         std::vector<float> host(nsave);
+        // intermediate dumps ride on the same chunking (.cu:3484-3492, 3535-3546, 3613-3670)
+        const bool inter = simulate_density_gradients && save_intermediate_ray_data && num_intermediate_positions_save > 0;
+        const size_t ninter = inter ? nsave * (size_t)num_intermediate_positions_save : 0;
+        std::vector<float> host_inter(ninter);
+        if (inter) {
+            PH_VOID(hipMalloc((void **)&d_ipos, ninter * sizeof(float)));
+            PH_VOID(hipMalloc((void **)&d_idir, ninter * sizeof(float)));
+        }
         const long long kmax = (num_particles + chunk - 1) / chunk;
         rc = begin_accumulate(scene, nullptr);
         for (long long k = 0; k < kmax && rc == 0; k++) {
             PH_VOID(hipMemset(d_fpos, 0xFF, nsave * sizeof(float)));    // all-ones = NaN (.cu:3527-3533)
             PH_VOID(hipMemset(d_fdir, 0xFF, nsave * sizeof(float)));
-            const DumpDev dump{d_fpos, d_fdir, num_lightrays_save};
+            if (inter) {
+                PH_VOID(hipMemset(d_ipos, 0xFF, ninter * sizeof(float)));
+                PH_VOID(hipMemset(d_idir, 0xFF, ninter * sizeof(float)));
+            }
+            const DumpDev dump{d_fpos, d_fdir, num_lightrays_save, d_ipos, d_idir, inter ? num_intermediate_positions_save : 0};
             rc = launch_chunk(scene, vol, ray_tracing_algorithm, k * chunk, std::min(num_particles, (k + 1) * chunk),
                               dump, nullptr, false);
             if (rc) break;
@@ -984,9 +1005,18 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
             write_dump(lightray_position_save_path, "pos_", (int)k, host);
             PH_VOID(hipMemcpy(host.data(), d_fdir, nsave * sizeof(float), hipMemcpyDeviceToHost));
             write_dump(lightray_direction_save_path, "dir_", (int)k, host);
+            if (inter) {
+                PH_VOID(hipMemcpy(host_inter.data(), d_ipos, ninter * sizeof(float), hipMemcpyDeviceToHost));
+                write_dump(lightray_position_save_path, "intermediate_pos_", (int)k, host_inter);
+                PH_VOID(hipMemcpy(host_inter.data(), d_idir, ninter * sizeof(float), hipMemcpyDeviceToHost));
+                write_dump(lightray_direction_save_path, "intermediate_dir_", (int)k, host_inter);
+            }
         }
         if (rc == 0) rc = end_accumulate(scene, d_image, nullptr);
     } else {
+        if (simulate_density_gradients && save_intermediate_ray_data)
+            fprintf(stderr, "photon: warning: save_intermediate_ray_data needs save_lightrays with num_lightrays_save > 0 "
+                            "(the reference sizes the intermediate buffers by it, .cu:3488); nothing recorded\n");
         rc = photon_trace(scene, vol, ray_tracing_algorithm, 0, num_particles, d_image, nullptr, nullptr);
     }
     if (rc) {

@@ -184,3 +184,33 @@ def test_image_is_linear_in_source_radiance(oracle):
     call.src_radiance = call.src_radiance * 2.0
     b, _ = oracle.render(call)
     assert np.allclose(b, 2.0 * a, rtol=1e-6)
+
+
+@pytest.mark.parametrize("algorithm", [1, 2])
+def test_intermediate_dumps_trace_the_march(oracle, tmp_path, algorithm):
+    """save_intermediate_ray_data (.h:784-790, 1004-1008; .cu:3613-3670): slot i holds the ray at the
+    start of march iteration i, so consecutive slots are one optical step apart and slot 0 is the
+    entry point on the volume's bounding box."""
+    from photon_amd import scenes
+    rho, sp, org = scenes.bos_volume(32)
+    nrrd = scenes.write_nrrd(str(tmp_path / "v.nrrd"), rho, sp, org)
+    slots = 8
+    call = scenes.bos_scene(n_dots=1, points_per_dot=10, rays_per_source=20, density_grad_filename=nrrd,
+                            ray_tracing_algorithm=algorithm)
+    call.save_lightrays, call.num_lightrays_save = True, call.num_rays
+    call.save_intermediate_ray_data, call.num_intermediate_positions_save = True, slots
+    call.lightray_position_save_path = call.lightray_direction_save_path = str(tmp_path)
+    oracle.render(call, interpolation=1)
+    pos = np.fromfile(tmp_path / "intermediate_pos_0000.bin", np.float32).reshape(call.num_rays, slots, 3)
+    dirs = np.fromfile(tmp_path / "intermediate_dir_0000.bin", np.float32).reshape(call.num_rays, slots, 3)
+    assert np.isfinite(pos).all() and np.isfinite(dirs).all()
+    np.testing.assert_allclose(np.linalg.norm(dirs, axis=2), 1.0, rtol=1e-5)
+    vol = oracle.volume_load_nrrd(nrrd, 1)
+    info = vol.info()
+    step = np.linalg.norm(np.diff(pos.astype(np.float64), axis=1), axis=2)
+    np.testing.assert_allclose(step[:, 1:], info.step_size, rtol=2e-3)     # ds = step/n, n ~ 1.0003
+    on_face = np.isclose(pos[:, 0, 2], info.max_bound[2], rtol=1e-5) | np.isclose(pos[:, 0, 2], info.min_bound[2], rtol=1e-5)
+    assert on_face.all()
+    # cubic: nothing recorded
+    oracle.render(call, interpolation=2)
+    assert np.isnan(np.fromfile(tmp_path / "intermediate_pos_0000.bin", np.float32)).all()

@@ -259,6 +259,44 @@ def test_ray_dumps_bit_exact(photon, oracle, small_volume_file, tmp_path):
     assert np.isfinite(np.fromfile(outs["gpu"][0] / "pos_0000.bin", np.float32)).any()
 
 
+@pytest.mark.parametrize("algorithm", [1, 2])
+def test_intermediate_ray_dumps_bit_exact(photon, oracle, small_volume_file, tmp_path, monkeypatch, algorithm):
+    """save_intermediate_ray_data: position / direction at the start of the first N march iterations
+    (reference .h:784-790, 1004-1008; files .cu:3613-3670), [ray][slot] float3, NaN = slot not reached."""
+    monkeypatch.setenv("PHOTON_INTERP", "linear")
+    slots = 12
+    call = scenes.bos_scene(n_dots=2, points_per_dot=20, rays_per_source=40, density_grad_filename=small_volume_file,
+                            ray_tracing_algorithm=algorithm)
+    call.source_point_number = 25                      # 40 sources -> 2 chunks
+    call.save_lightrays = True
+    call.num_lightrays_save = 25 * 40
+    call.save_intermediate_ray_data = True
+    call.num_intermediate_positions_save = slots
+    outs = {}
+    for tag, run in (("gpu", lambda c: photon.render(c)), ("cpu", lambda c: oracle.render(c, interpolation=1)[0])):
+        pdir, ddir = tmp_path / f"{tag}_pos", tmp_path / f"{tag}_dir"
+        pdir.mkdir()
+        ddir.mkdir()
+        call.lightray_position_save_path, call.lightray_direction_save_path = str(pdir), str(ddir)
+        run(call)
+        outs[tag] = (pdir, ddir)
+    for k in range(2):
+        for which, prefix in ((0, "intermediate_pos_"), (1, "intermediate_dir_")):
+            a = np.fromfile(outs["gpu"][which] / f"{prefix}{k:04d}.bin", np.float32)
+            b = np.fromfile(outs["cpu"][which] / f"{prefix}{k:04d}.bin", np.float32)
+            assert a.size == b.size == 25 * 40 * slots * 3
+            assert_bit_equal(a, b, f"{prefix}{k:04d}.bin")
+    pos = np.fromfile(outs["gpu"][0] / "intermediate_pos_0000.bin", np.float32).reshape(25 * 40, slots, 3)
+    assert np.isfinite(pos[:, 0]).all()                 # slot 0 = entry point on the volume's face
+    z = pos[0, :, 2]
+    dz = np.diff(z[np.isfinite(z)])
+    assert dz.size > 2 and (np.all(dz < 0) or np.all(dz > 0))      # marching monotonically through the volume
+    # the cubic branches do not record (as in the reference): files exist, every slot NaN
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    photon.render(call)
+    assert np.isnan(np.fromfile(outs["cpu"][0] / "intermediate_pos_0000.bin", np.float32)).all()
+
+
 def test_position_noise_hook(photon, oracle, monkeypatch):
     """add_pos_noise: seeded Gaussian jitter of the sensor hit (reference: time-seeded cuRAND, so
     only our two implementations can be compared).  Erf and 4-pixel splat paths."""
