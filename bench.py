@@ -32,6 +32,24 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/
 TEXELS_PER_SAMPLE = {1: 8, 2: 64}
 
 
+VALU_F32_PEAK_TFLOPS = 157.3     # MI355X vector f32 (256 CUs x 4 SIMD x 32 lanes/clk FMA x 2.4 GHz x 2)
+
+
+def measure_copy_bandwidth(nbytes: int = 1 << 30, reps: int = 5) -> float:
+    """Device-to-device copy rate (read + write bytes) in GB/s: the HBM rate a trivial kernel reaches here."""
+    import torch
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) * 1e-9
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +210,17 @@ def main():
                 "bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
                 "sensor_taps_per_ray": round(a_bar, 2),
                 "compulsory_bytes": int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources)}
+
+    # secondary views of the same launch: with the block staged through LDS the march is
+    # VALU/LDS-bound, so also price it against the f32 vector peak, and measure what a plain
+    # device-to-device copy reaches on this box ("achievable" HBM peak)
+    flops_per_sample = {"linear": 100.0, "cubic": 570.0}[args.interp]
+    flops = samples * flops_per_sample + iters * 120.0
+    tflops = flops / (march_ms_avg * 1e-3) * 1e-12 if march_ms_avg > 0 else 0.0
+    roofline["valu_f32"] = {"achieved": round(tflops, 2), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "flops_per_sample": flops_per_sample}
+    if rank == 0:
+        roofline["hbm_copy_measured_gbs"] = round(measure_copy_bandwidth(), 1)
 
     out = None
     if rank == 0:

@@ -300,51 +300,10 @@ __device__ __forceinline__ void euler(f3 &rpos, f3 &rdir, const VolumeDev &v, f3
 }
 
 // =============================================================================================
-// Wave-packed samplers.
-//
-// Rays are laid out source-major, so the 64 lanes of a wave start at one light-field source and
-// stay within a fraction of a texel of each other through the volume (ray_cone_pitch_ratio 1e-4 in
-// BOS; a few texels for a full PIV cone).  Almost every sample of a wave therefore needs the SAME
-// 4x4x4 (tricubic) or 2x2x2 (trilinear) texel block with per-lane weights.  The packed samplers
-// exploit that: lanes are grouped by base texel (a waterfall over readfirstlane); for each group the
-// block is addressed with wave-uniform indices, which the compiler turns into scalar (SMEM)
-// loads -- the 64 texels (1 KiB) arrive once per wave through the scalar cache instead of 64 x 64
-// times through the vector memory path -- and the per-lane fmaf chains take the texels as SGPR
-// operands.  Lanes near the volume faces (clamped addressing) and waves that are not coherent
-// (more than kPackedGroups distinct texel blocks) fall back to the per-lane gather.  The arithmetic
-// is the same fmaf chain in the same order on every path: results are bit-identical.
+// Per-lane building blocks shared with the wave-cooperative samplers (device_volume_coop.hpp).
 // =============================================================================================
-constexpr int kPackedGroups = 4;
 
-// Separable 64-tap sum for ONE texel block addressed with wave-uniform (i,j,k) = floor(coord-0.5):
-// the block is interior (no clamping), rows are 64 contiguous bytes -> s_load_dwordx16 each.
-__device__ __forceinline__ f4 cubic_taps_uniform(const f4 *__restrict__ tex, int nx, int ny, int i, int j, int k,
-                                                 const float (&wx)[4], const float (&wy)[4], const float (&wz)[4]) {
-    const size_t W = nx, WH = (size_t)nx * ny;
-    f4 acc = f4{0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        f4 plane = f4{0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const f4 *row = tex + (size_t)(k - 1 + c) * WH + (size_t)(j - 1 + b) * W + (i - 1);
-            const f4 t0 = ldtexel(row), t1 = ldtexel(row + 1), t2 = ldtexel(row + 2), t3 = ldtexel(row + 3);
-            f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
-            r = f4{fmaf(wx[1], t1.x, r.x), fmaf(wx[1], t1.y, r.y), fmaf(wx[1], t1.z, r.z), fmaf(wx[1], t1.w, r.w)};
-            r = f4{fmaf(wx[2], t2.x, r.x), fmaf(wx[2], t2.y, r.y), fmaf(wx[2], t2.z, r.z), fmaf(wx[2], t2.w, r.w)};
-            r = f4{fmaf(wx[3], t3.x, r.x), fmaf(wx[3], t3.y, r.y), fmaf(wx[3], t3.z, r.z), fmaf(wx[3], t3.w, r.w)};
-            if (b == 0) plane = f4{wy[0] * r.x, wy[0] * r.y, wy[0] * r.z, wy[0] * r.w};
-            else plane = f4{fmaf(wy[b], r.x, plane.x), fmaf(wy[b], r.y, plane.y), fmaf(wy[b], r.z, plane.z),
-                            fmaf(wy[b], r.w, plane.w)};
-        }
-        if (c == 0) acc = f4{wz[0] * plane.x, wz[0] * plane.y, wz[0] * plane.z, wz[0] * plane.w};
-        else acc = f4{fmaf(wz[c], plane.x, acc.x), fmaf(wz[c], plane.y, acc.y), fmaf(wz[c], plane.z, acc.z),
-                      fmaf(wz[c], plane.w, acc.w)};
-    }
-    return acc;
-}
-
-// The same sum with per-lane, clamped addressing (volume faces, incoherent waves).  Deliberately
+// The 64-tap separable sum with per-lane, clamped addressing (incoherent waves).  Deliberately
 // NOT inlined: it is the rare path, and inlined at three call sites its 64 loads in flight would
 // set the register budget (and so the occupancy) of the whole march kernel.
 // (It recomputes the B-spline weights from the coordinate -- same operations, same values -- so a
@@ -386,39 +345,6 @@ __device__ __attribute__((noinline)) f4 cubic_gather_fn(const f4 *__restrict__ t
     return acc;
 }
 
-__device__ __forceinline__ f4 tex3d_cubic_packed(const VolumeDev &v, const f4 *__restrict__ tex, float x, float y,
-                                                 float z) {
-    const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
-    const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
-    float wx[4], wy[4], wz[4];
-    bspline_weights(xg - fi, wx[0], wx[1], wx[2], wx[3]);
-    bspline_weights(yg - fj, wy[0], wy[1], wy[2], wy[3]);
-    bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
-    const int bi = (int)fi, bj = (int)fj, bk = (int)fk;
-    const bool interior = bi >= 1 && bi + 2 <= v.nx - 1 && bj >= 1 && bj + 2 <= v.ny - 1 && bk >= 1 &&
-                          bk + 2 <= v.nz - 1;
-    f4 acc = f4{0, 0, 0, 0};
-    bool done = !interior;              // face texels need clamping: per-lane gather below
-#pragma unroll 1
-    for (int g = 0; g < kPackedGroups; g++) {
-        if (done) break;
-        const int ci = __builtin_amdgcn_readfirstlane(bi), cj = __builtin_amdgcn_readfirstlane(bj),
-                  ck = __builtin_amdgcn_readfirstlane(bk);
-        // The addressing copies go through an empty asm so the optimiser cannot use `bi == ci` to
-        // substitute the per-lane index back in (GVN equality propagation would turn the scalar
-        // loads into 64 vector loads again).
-        int ai = ci, aj = cj, ak = ck;
-        asm volatile("" : "+s"(ai), "+s"(aj), "+s"(ak));
-        if (bi == ci && bj == cj && bk == ck) {         // this lane belongs to the leader's texel block
-            acc = cubic_taps_uniform(tex, v.nx, v.ny, ai, aj, ak, wx, wy, wz);
-            done = true;
-        }
-    }
-    if (!interior || !done)             // volume faces, or an incoherent wave (> kPackedGroups blocks)
-        acc = cubic_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);
-    return acc;
-}
-
 template <bool CLAMP>
 __device__ __forceinline__ f4 linear_taps(const f4 *__restrict__ t, int nx, int ny, int nz, int i, int j, int k,
                                           float a, float b, float c) {
@@ -434,121 +360,6 @@ __device__ __forceinline__ f4 linear_taps(const f4 *__restrict__ t, int nx, int 
     const f4 c01 = lerp4(v001, v101, a), c11 = lerp4(v011, v111, a);
     const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
     return lerp4(c0, c1, c);
-}
-
-__device__ __forceinline__ f4 tex3d_linear_packed(const VolumeDev &v, const f4 *__restrict__ tex, float x, float y,
-                                                  float z) {
-    const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
-    const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
-    const float a = xb - fi, b = yb - fj, c = zb - fk;
-    const int bi = (int)fi, bj = (int)fj, bk = (int)fk;
-    const bool interior = bi >= 0 && bi + 1 <= v.nx - 1 && bj >= 0 && bj + 1 <= v.ny - 1 && bk >= 0 &&
-                          bk + 1 <= v.nz - 1;
-    f4 acc = f4{0, 0, 0, 0};
-    bool done = !interior;
-#pragma unroll 1
-    for (int g = 0; g < kPackedGroups; g++) {
-        if (done) break;
-        const int ci = __builtin_amdgcn_readfirstlane(bi), cj = __builtin_amdgcn_readfirstlane(bj),
-                  ck = __builtin_amdgcn_readfirstlane(bk);
-        int ai = ci, aj = cj, ak = ck;
-        asm volatile("" : "+s"(ai), "+s"(aj), "+s"(ak));
-        if (bi == ci && bj == cj && bk == ck) {
-            acc = linear_taps<false>(tex, v.nx, v.ny, v.nz, ai, aj, ak, a, b, c);
-            done = true;
-        }
-    }
-    if (!interior || !done) acc = linear_taps<true>(tex, v.nx, v.ny, v.nz, bi, bj, bk, a, b, c);
-    return acc;
-}
-
-// RK4 with ONE sampler call site: the three stages of an iteration (Sharma's A, B, C) run through
-// the same code with a per-lane stage counter, so the (large) sampler body is instantiated once.
-// Operation order per ray is that of rk4<> above / the reference (.h:952-1291).
-template <int INTERP>
-__device__ __forceinline__ void rk4_packed(f3 &rpos, f3 &rdir, const VolumeDev &v, const f4 *__restrict__ tex,
-                                           f3 scale, MarchCount &mc) {
-    const float ambient = 1.000277;
-    int loop_ctr = 0, spins = 0, stage = 0;
-    f3 spos = rpos, R_n = rpos, T_n = rdir, A = mk3(0, 0, 0), B = mk3(0, 0, 0);
-    f4 val_prev = f4{0, 0, 0, 0};
-    float delta_t = 0.f, current_n = 1.f;
-    while (true) {
-        if (stage == 0 && loop_ctr > kLoopMax) break;
-        const f3 lookup = lookup_index(spos, v, scale);
-        const bool in = inside_box(spos, v, lookup);
-        if (stage == 0) {
-            if (!in && loop_ctr != 0) break;
-            if (!can_access(v, lookup)) {
-                spos = spos + v.step_size / (1 + v.data_min) * rdir;
-                rpos = spos;
-                if (++spins > kSpinMax) break;
-                continue;
-            }
-        } else if (!in) {
-            break;
-        }
-        f4 val = INTERP == 1 ? tex3d_linear_packed(v, tex, lookup.x, lookup.y, lookup.z)
-                             : tex3d_cubic_packed(v, tex, lookup.x, lookup.y, lookup.z);
-        mc.samples++;
-        if (val.w < v.data_min) {
-            if (INTERP == 1) {                          // .h:1056-1065 / 1110-1119 / 1149-1158
-                if (val_prev.w == 0) {
-                    const f4 t = tex3d_linear_packed(v, tex, lookup.x, lookup.y, lookup.z - 1);
-                    mc.samples++;
-                    val = f4{t.x, t.y, t.z, ambient - 1};
-                } else {
-                    val = val_prev;
-                }
-            } else if (stage == 0) {                    // .h:1220-1227 (first sample only)
-                spos = spos + v.step_size / (1 + v.data_min) * rdir;
-                rpos = spos;
-                if (++spins > kSpinMax) break;
-                continue;
-            }
-        }
-        val.w += 1;
-        const f3 D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
-        if (stage == 0) {
-            loop_ctr += 1;
-            current_n = val.w;
-            R_n = spos;
-            delta_t = v.step_size / val.w;
-            T_n = val.w * rdir;
-            A = delta_t * D;
-            spos = R_n + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;
-            stage = 1;
-        } else if (stage == 1) {
-            B = delta_t * D;
-            spos = R_n + delta_t * T_n + (0.5f * delta_t) * B;
-            stage = 2;
-        } else {
-            const f3 C = delta_t * D;
-            R_n = R_n + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));
-            T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);
-            rpos = R_n;
-            rdir = normalize(T_n / (INTERP == 1 ? current_n : val.w));
-            spos = R_n;
-            stage = 0;
-            mc.iterations++;
-        }
-        if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
-    }
-}
-
-template <int ALGO, int INTERP>
-__device__ __forceinline__ void trace_volume_packed(f3 &pos_io, f3 &dir_io, const VolumeDev &v,
-                                                    const f4 *__restrict__ tex, MarchCount &mc) {
-    const f3 mn = v.min_bound, mx = v.max_bound;
-    const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
-    f3 pos = pos_io;
-    const f3 dir = dir_io;
-    if (pos.x <= mn.x || pos.y <= mn.y || pos.z <= mn.z || pos.x >= mx.x || pos.y >= mx.y || pos.z >= mx.z) {
-        if (!intersect_with_volume(pos, dir, mn, mx)) return;
-    }
-    pos_io = pos;
-    if (ALGO == 1) euler<INTERP>(pos_io, dir_io, v, scale, mc);
-    else rk4_packed<INTERP>(pos_io, dir_io, v, tex, scale, mc);
 }
 
 // trace_rays_through_density_gradients (.h:1455-1544): entry test + integrator dispatch.

@@ -28,9 +28,6 @@
 
 namespace photon {
 
-#ifndef PHOTON_LDS_ROWS_IN_FLIGHT
-#define PHOTON_LDS_ROWS_IN_FLIGHT 4      // texel rows (x4 texels x4 VGPRs) read ahead of the FMAs: 4 = one z-slab
-#endif
 
 #ifndef PHOTON_COOP_GROUPS
 #define PHOTON_COOP_GROUPS 4
@@ -43,40 +40,54 @@ namespace photon {
 #endif
 constexpr int kCoopGroups = PHOTON_COOP_GROUPS;      // distinct texel blocks served cooperatively per sample
 
-// 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each
-// texel is one ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues in
-// 4 cycles against 2 for v_fma_f32 (measured, build/ubench/fma_rate.hip), so packing buys no
+// 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
+// is one broadcast ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues
+// in 4 cycles against 2 for v_fma_f32 (measured, build/ubench/fma_rate.hip), so packing buys no
 // throughput and costs the (w,w) operand splats; the library is built with -fno-slp-vectorize.
-__device__ __forceinline__ f4 cubic_slab_lds(const f4 *q, const float (&wx)[4], const float (&wy)[4]) {
-    f4 plane = f4{0, 0, 0, 0};
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        if (PHOTON_LDS_ROWS_IN_FLIGHT == 2 && b == 2) asm volatile("" ::: "memory");
-        const f4 *row = q + b * 4;
-        const f4 t0 = ldtexel(row), t1 = ldtexel(row + 1), t2 = ldtexel(row + 2), t3 = ldtexel(row + 3);
-        f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
-        r = f4{fmaf(wx[1], t1.x, r.x), fmaf(wx[1], t1.y, r.y), fmaf(wx[1], t1.z, r.z), fmaf(wx[1], t1.w, r.w)};
-        r = f4{fmaf(wx[2], t2.x, r.x), fmaf(wx[2], t2.y, r.y), fmaf(wx[2], t2.z, r.z), fmaf(wx[2], t2.w, r.w)};
-        r = f4{fmaf(wx[3], t3.x, r.x), fmaf(wx[3], t3.y, r.y), fmaf(wx[3], t3.z, r.z), fmaf(wx[3], t3.w, r.w)};
-        if (b == 0) plane = f4{wy[0] * r.x, wy[0] * r.y, wy[0] * r.z, wy[0] * r.w};
-        else plane = f4{fmaf(wy[b], r.x, plane.x), fmaf(wy[b], r.y, plane.y), fmaf(wy[b], r.z, plane.z),
-                        fmaf(wy[b], r.w, plane.w)};
-    }
-    return plane;
-}
-
+//
+// Written as a rolling pipeline over the 16 texel rows: the reads of row r+PHOTON_LDS_AHEAD are issued
+// before the FMAs of row r, so a wave keeps the LDS pipe and the VALU busy at the same time instead of
+// alternating "read a slab / wait / 84 FMAs" (C3: 83.9 -> 80.0 ms).  The asm statements pin that
+// order -- left alone the scheduler hoists all 64 reads to the top (256 VGPRs of texels, one wave per
+// SIMD); LDS returns data in order, so the compiler's s_waitcnt lgkmcnt(N) lets row r start while the
+// later rows are still in flight.
+#ifndef PHOTON_LDS_AHEAD
+#define PHOTON_LDS_AHEAD 1          // rows read ahead (16 VGPRs each); 1, 2, 3 measure the same, 1 is the leanest
+#endif
 __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4], const float (&wy)[4],
-                                             const float (&wz)[4]) {
-    f4 p = cubic_slab_lds(blk, wx, wy);
-    f4 acc = f4{wz[0] * p.x, wz[0] * p.y, wz[0] * p.z, wz[0] * p.w};
-    // A compiler memory barrier between z-slabs: without it the scheduler hoists all 64 texel
-    // reads to the top (256 VGPRs in flight, one wave per SIMD).  One slab = 16 reads = 64 VGPRs
-    // covers the LDS latency.
+                                                  const float (&wz)[4]) {
+    constexpr int D = PHOTON_LDS_AHEAD + 1;                     // ring of rows in registers
+    f4 t[D][4];
 #pragma unroll
-    for (int c = 1; c < 4; c++) {
+    for (int r = 0; r < PHOTON_LDS_AHEAD; r++) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) t[r % D][a] = ldtexel(blk + r * 4 + a);
+    }
+    f4 acc = f4{0, 0, 0, 0}, plane = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (r + PHOTON_LDS_AHEAD < 16) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) t[(r + PHOTON_LDS_AHEAD) % D][a] = ldtexel(blk + (r + PHOTON_LDS_AHEAD) * 4 + a);
+        }
         asm volatile("" ::: "memory");
-        p = cubic_slab_lds(blk + c * 16, wx, wy);
-        acc = f4{fmaf(wz[c], p.x, acc.x), fmaf(wz[c], p.y, acc.y), fmaf(wz[c], p.z, acc.z), fmaf(wz[c], p.w, acc.w)};
+        const int b = r & 3, c = r >> 2;
+        const f4 t0 = t[r % D][0], t1 = t[r % D][1], t2 = t[r % D][2], t3 = t[r % D][3];
+        f4 q = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
+        q = f4{fmaf(wx[1], t1.x, q.x), fmaf(wx[1], t1.y, q.y), fmaf(wx[1], t1.z, q.z), fmaf(wx[1], t1.w, q.w)};
+        q = f4{fmaf(wx[2], t2.x, q.x), fmaf(wx[2], t2.y, q.y), fmaf(wx[2], t2.z, q.z), fmaf(wx[2], t2.w, q.w)};
+        q = f4{fmaf(wx[3], t3.x, q.x), fmaf(wx[3], t3.y, q.y), fmaf(wx[3], t3.z, q.z), fmaf(wx[3], t3.w, q.w)};
+        if (b == 0) plane = f4{wy[0] * q.x, wy[0] * q.y, wy[0] * q.z, wy[0] * q.w};
+        else plane = f4{fmaf(wy[b], q.x, plane.x), fmaf(wy[b], q.y, plane.y), fmaf(wy[b], q.z, plane.z),
+                        fmaf(wy[b], q.w, plane.w)};
+        if (b == 3) {
+            if (c == 0) acc = f4{wz[0] * plane.x, wz[0] * plane.y, wz[0] * plane.z, wz[0] * plane.w};
+            else acc = f4{fmaf(wz[c], plane.x, acc.x), fmaf(wz[c], plane.y, acc.y), fmaf(wz[c], plane.z, acc.z),
+                          fmaf(wz[c], plane.w, acc.w)};
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
+        } else {
+            asm volatile("" : "+v"(plane.x), "+v"(plane.y), "+v"(plane.z), "+v"(plane.w) : : "memory");
+        }
     }
     return acc;
 }
@@ -187,8 +198,15 @@ struct MarchU {
     float step, data_min, spin_step;            // h, min(n-1), h / (1 + data_min)
     int nx, ny, nz;
 };
+// Inline asm on purpose: the builtin is folded away when the compiler can prove its operand uniform,
+// which leaves a VALU-computed float (cvt, div) in a VGPR for the whole loop -- or in scratch.
+// The s_nops cover the gfx940+ hazards the compiler cannot see through inline asm (VALU writes VGPR ->
+// readlane reads it: 1 wait state; VALU writes SGPR -> VALU / VMEM reads it: 2 / 5 wait states); this
+// runs once per kernel, in the prologue.
 __device__ __forceinline__ float uniformf(float x) {
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+    float s;
+    asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(s) : "v"(x));
+    return s;
 }
 __device__ __forceinline__ MarchU make_march_consts(const VolumeDev &v, f3 scale) {
     MarchU u;
@@ -216,20 +234,31 @@ __device__ __forceinline__ bool inside_box_u(f3 p, const MarchU &u, f3 l) {
     return can_access_u(u, l);
 }
 
+// Statistics.  MarchCount (device_volume.hpp) counts per lane -- photon_trace_volume_rays reports
+// the steps of each ray.  The render kernels only need totals: WaveCount keeps them wave-uniform (SALU
+// popcount of the ballot, SGPR accumulators), which takes two VGPRs and two VALU adds per sample out
+// of the hot loop.  Must be called at wave-uniform points.
+struct WaveCount { unsigned iterations; unsigned samples; };
+__device__ __forceinline__ void count_samples(MarchCount &mc, bool yes) { if (yes) mc.samples++; }
+__device__ __forceinline__ void count_iterations(MarchCount &mc, bool yes) { if (yes) mc.iterations++; }
+__device__ __forceinline__ void count_samples(WaveCount &mc, bool yes) { mc.samples += (unsigned)__popcll(__ballot(yes)); }
+__device__ __forceinline__ void count_iterations(WaveCount &mc, bool yes) { mc.iterations += (unsigned)__popcll(__ballot(yes)); }
+
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
-template <int INTERP>
+template <int INTERP, class CNT>
 __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need, f3 lookup,
-                                          const f4 &val_prev, MarchCount &mc, int &tile_key) {
+                                          const f4 &val_prev, CNT &mc, int &tile_key) {
     f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z)
                          : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, tile_key);
-    if (need) mc.samples++;
+    count_samples(mc, need);
     if (INTERP == 1) {
         const float ambient = 1.000277;
         const bool low = need && val.w < v.data_min;
         const bool repair = low && val_prev.w == 0;
         if (__ballot(repair) != 0) {                            // wave-uniform, rare
             const f4 t = tex3d_linear_coop(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1);
-            if (repair) { mc.samples++; val = f4{t.x, t.y, t.z, ambient - 1}; }
+            count_samples(mc, repair);
+            if (repair) val = f4{t.x, t.y, t.z, ambient - 1};
         }
         if (low && !repair) val = val_prev;
     }
@@ -256,9 +285,9 @@ __device__ __forceinline__ void record_intermediate(const InterDump &d, int loop
     }
 }
 
-template <int INTERP, bool SAVE>
+template <int INTERP, bool SAVE, class CNT>
 __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
-                                         const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc,
+                                         const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
                                          const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0, tile_key = -1;
@@ -285,7 +314,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
                 }
             }
         }
-        f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         bool go = false;                                        // lane continues to samples B and C
         if (need) {
             if (INTERP == 2 && val.w < u.data_min) {            // .h:1220-1227
@@ -310,7 +339,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1094-1101
             else need = true;
         }
-        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         if (need) {
             val.w += 1;
             B = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
@@ -324,7 +353,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1135-1141
             else need = true;
         }
-        val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
         if (need) {
             val.w += 1;
             const f3 C = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
@@ -332,8 +361,8 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);                      // .h:1170
             rdir = normalize(T_n / (INTERP == 1 ? current_n : val.w));              // .h:1178 / 1276
             if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
-            mc.iterations++;
         }
+        count_iterations(mc, need);
     }
 }
 
@@ -343,9 +372,9 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
 struct GradNoise { int on; float std; unsigned long long seed, ray_id; };
 
 
-template <int INTERP, bool SAVE>
+template <int INTERP, bool SAVE, class CNT>
 __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
-                                           const f4 *__restrict__ tex, f4 *blk, f3 scale, MarchCount &mc,
+                                           const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
                                            const GradNoise &gn, const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0, tile_key = -1;
@@ -369,7 +398,8 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
                 }
             }
         }
-        f4 val = sample_coop<INTERP>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        bool stepped = false;
         if (need) {
             if (INTERP == 1) {
                 const float current_n = 1 + val.w;
@@ -383,7 +413,7 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
                 rpos = rpos + u.step / current_n * rdir;                // .h:875
                 val_prev = val;
                 loop_ctr += 1;
-                mc.iterations++;
+                stepped = true;
             } else if (val.w < u.data_min) {                            // .h:916-923
                 rpos = rpos + u.spin_step * rdir;
                 if (++spins > kSpinMax) active = false;
@@ -392,17 +422,18 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
                 rdir = normalize(rdir + u.step * mk3(val.x, val.y, val.z));     // .h:931-933
                 const float n = 1 + val.w;
                 rpos = rpos + rdir * u.step / n;                        // .h:939
-                mc.iterations++;
+                stepped = true;
             }
         }
+        count_iterations(mc, stepped);
     }
 }
 
 // trace_rays_through_density_gradients (.h:1455-1544), wave-synchronous.  has_ray = this lane
 // carries a ray at all (tail lanes of the last workgroup do not).
-template <int ALGO, int INTERP, bool SAVE>
+template <int ALGO, int INTERP, bool SAVE, class CNT>
 __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &dir_io, const VolumeDev &v,
-                                                  const f4 *__restrict__ tex, f4 *blk, MarchCount &mc,
+                                                  const f4 *__restrict__ tex, f4 *blk, CNT &mc,
                                                   const GradNoise &gn, const InterDump &idump) {
     const f3 mn = v.min_bound, mx = v.max_bound;
     const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
@@ -415,8 +446,8 @@ __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &
         }
         if (active) pos_io = pos;
     }
-    if (ALGO == 1) euler_coop<INTERP, SAVE>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump);
-    else rk4_coop<INTERP, SAVE>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump);
+    if (ALGO == 1) euler_coop<INTERP, SAVE, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump);
+    else rk4_coop<INTERP, SAVE, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump);
 }
 
 }  // namespace photon

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
     MarchCount mc{0, 0};
     const GradNoise no_noise{0, 0.f, 0ull, 0ull};
     const InterDump no_dump{nullptr, nullptr, 0, 0, 0u};
-    trace_volume_coop<ALGO, INTERP, false>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
+    trace_volume_coop<ALGO, INTERP, false, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
     if (has_ray) {
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
         dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDe
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
     const bool has_ray = r < n_rays;
-    MarchCount mc{0, 0};
+    WaveCount mc{0u, 0u};                                       // wave-uniform totals (SGPRs)
     f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
     if (has_ray) {
         p = mk3(st.px[r], st.py[r], st.pz[r]);
@@ -279,13 +279,15 @@ __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDe
     }
     const GradNoise gn{noise.add_ngrad, noise.ngrad_std, noise.seed, ray_base + r};
     idump.ray = r;                                              // chunk-global ray id, like the final dumps
-    trace_volume_coop<ALGO, INTERP, SAVE>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
+    trace_volume_coop<ALGO, INTERP, SAVE, WaveCount>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
     if (has_ray) {
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
     }
-    wave_add(&counters[CNT_ITER], (unsigned long long)mc.iterations);
-    wave_add(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
+    if ((threadIdx.x & 63) == 0) {
+        if (mc.iterations) atomicAdd(&counters[CNT_ITER], (unsigned long long)mc.iterations);
+        if (mc.samples) atomicAdd(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
+    }
 }
 
 // Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241).  FROM_STATE=false
