@@ -117,8 +117,9 @@ typedef struct camera_design_t {
  *   image_array        f32[H*W], row-major row*W+col, READ-MODIFY-WRITE (accumulates on
  *                      the caller's contents, .cu:3309,3675)
  *   element_center     f64[num_elements][3]; element_plane_parameters f64[num_elements][4]
- *   ray_tracing_algorithm  1 euler, 2 rk4 (3 rk45 / 4 adams-bashforth: not built yet ->
- *                      reported on stderr, image left untouched)
+ *   ray_tracing_algorithm  1 euler, 2 rk4, 3 rk45, 4 adams-bashforth; any other value leaves the ray
+ *                      straight (the reference's `default: break`, trace_rays_...h:1537).  3 and 4
+ *                      are restated literally, trilinear on the raw volume whatever PHOTON_INTERP
  *   density_grad_filename  NRRD (type float, dim 3, raw little-endian), "" when unused
  *   save_lightrays     writes <pos_path>/pos_%04d.bin, <dir_path>/dir_%04d.bin per chunk
  * All pointers are borrowed for the duration of the call.  No error channel (void):

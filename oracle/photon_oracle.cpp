@@ -614,6 +614,211 @@ void euler(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc, const 
     }
 }
 
+// rk45, trace_rays_through_density_gradients.h:304-718: Runge-Kutta-Fehlberg 4(5) with step-size
+// control on trilinear fetches of the raw volume (there is no cubic branch).  Restated literally,
+// including what looks unintended: the texture's .w is n-1, but after the first accepted step it is
+// used as the refractive index itself (:689), and a ray that starts ON a max face (where
+// IntersectWithVolume puts every ray entering through one) fails the first inside test, shrinks h
+// once to 0.09997 step and stops (:397-419) -- for such rays the integrator is a no-op.
+// One deliberate difference: powf(x, 0.25f) (:668, not correctly rounded in any libm) is evaluated
+// as sqrtf(sqrtf(x)), which is, so that the CPU and the GPU agree bit for bit.
+void rk45(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
+    const float tol = 1e-3;
+    float refractive_index = 1.000277;
+    float h = v.step_size / refractive_index;
+    f3 pos = rpos, dir = rdir;
+    f3 lookup, R_n, T_n;
+    f4 val;
+    f3 k1, k2, k3, k4, k5, k6, y4, y5, l1, l2, l3, l4, l5, l6, z4, z5;
+    int loop_ctr = 0;
+    // a stage point outside the volume: h /= 10, retry while h >= floor * step, else stop (:397-419 ...)
+    auto shrink = [&](double floor_frac) {
+        h = (float)(h / 10.0);
+        return (double)h >= floor_frac * v.step_size;
+    };
+    auto fetch = [&](f3 l) { mc.samples++; return tex3d_linear(v, v.data, l.x, l.y, l.z); };
+    while (true) {
+        loop_ctr += 1;
+        if (loop_ctr > 100000) break;                                   // :358
+        R_n = pos;
+        T_n = refractive_index * dir;
+        k1 = h * T_n;
+        lookup = lookup_index(R_n, v, scale);
+        if (!inside_box(R_n, v, lookup)) { if (shrink(0.1)) continue; else break; }
+        val = fetch(lookup);
+        if (val.w < v.data_min) {                                       // :425-430
+            pos = pos + v.step_size / v.data_min * dir;
+            rpos = pos;
+            continue;
+        }
+        l1 = (h * val.w) * mk3(val.x, val.y, val.z);
+        R_n = pos + k1 / (float)4.0;
+        T_n = refractive_index * dir + l1 / (float)4.0;
+        k2 = h * T_n;
+        lookup = lookup_index(R_n, v, scale);
+        if (!inside_box(R_n, v, lookup)) { if (shrink(0.1)) continue; else break; }
+        val = fetch(lookup);
+        l2 = (h * val.w) * mk3(val.x, val.y, val.z);
+        R_n = pos + (float)(3.0 / 32.0) * k1 + (float)(9.0 / 32.0) * k2;
+        T_n = refractive_index * dir + (float)(3.0 / 32.0) * l1 + (float)(9.0 / 32.0) * l2;
+        k3 = h * T_n;
+        lookup = lookup_index(R_n, v, scale);
+        if (!inside_box(R_n, v, lookup)) { if (shrink(0.1)) continue; else break; }
+        val = fetch(lookup);
+        l3 = (h * val.w) * mk3(val.x, val.y, val.z);
+        R_n = pos + (float)(1932.0 / 2197.0) * k1 - (float)(7200.0 / 2197.0) * k2 + (float)(7296.0 / 2197.0) * k3;
+        T_n = refractive_index * dir + (float)(1932.0 / 2197.0) * l1 - (float)(7200.0 / 2197.0) * l2 +
+              (float)(7296.0 / 2197.0) * l3;
+        k4 = h * T_n;
+        lookup = lookup_index(R_n, v, scale);
+        if (!inside_box(R_n, v, lookup)) { if (shrink(0.1)) continue; else break; }
+        val = fetch(lookup);
+        l4 = (h * val.w) * mk3(val.x, val.y, val.z);
+        R_n = pos + (float)(439.0 / 216.0) * k1 - (float)8.0 * k2 + (float)(3680.0 / 513.0) * k3 -
+              (float)(845.0 / 4104.0) * k4;
+        T_n = refractive_index * dir + (float)(439.0 / 216.0) * l1 - (float)8.0 * l2 + (float)(3680.0 / 513.0) * l3 -
+              (float)(845.0 / 4104.0) * l4;
+        k5 = h * T_n;
+        lookup = lookup_index(R_n, v, scale);
+        if (!inside_box(R_n, v, lookup)) { if (shrink(0.1)) continue; else break; }
+        val = fetch(lookup);
+        l5 = (h * val.w) * mk3(val.x, val.y, val.z);
+        R_n = pos - (float)(8.0 / 27.0) * k1 + (float)2.0 * k2 - (float)(3544.0 / 2565.0) * k3 +
+              (float)(1859.0 / 4104.0) * k4 - (float)(11.0 / 40.0) * k5;
+        T_n = refractive_index * dir - (float)(8.0 / 27.0) * l1 + (float)2.0 * l2 - (float)(3544.0 / 2565.0) * l3 +
+              (float)(1859.0 / 4104.0) * l4 - (float)(11.0 / 40.0) * l5;
+        k6 = h * T_n;
+        lookup = lookup_index(R_n, v, scale);
+        if (!inside_box(R_n, v, lookup)) { if (shrink(0.01)) continue; else break; }    // :606: 0.01 here
+        val = fetch(lookup);
+        l6 = (h * val.w) * mk3(val.x, val.y, val.z);
+        y4 = pos + (float)(25.0 / 216.0) * k1 + (float)(1408.0 / 2565.0) * k3 + (float)(2197.0 / 4104.0) * k4 -
+             (float)(1.0 / 5.0) * k5;
+        y5 = pos + (float)(16.0 / 135.0) * k1 + (float)(6656.0 / 12825.0) * k3 + (float)(28561.0 / 56430.0) * k4 -
+             (float)(9.0 / 50.0) * k5 + (float)(2.0 / 55.0) * k6;
+        z4 = refractive_index * dir + (float)(25.0 / 216.0) * l1 + (float)(1408.0 / 2565.0) * l3 +
+             (float)(2197.0 / 4104.0) * l4 - (float)(1.0 / 5.0) * l5;
+        z5 = refractive_index * dir + (float)(16.0 / 135.0) * l1 + (float)(6656.0 / 12825.0) * l3 +
+             (float)(28561.0 / 56430.0) * l4 - (float)(9.0 / 50.0) * l5 + (float)(2.0 / 55.0) * l6;
+        const f3 dy = y4 - y5, dz = z4 - z5;
+        const float ih = 1 / h;
+        const f3 R0 = ih * mk3(fabsf(dy.x), fabsf(dy.y), fabsf(dy.z));     // :656-657
+        const f3 R1 = ih * mk3(fabsf(dz.x), fabsf(dz.y), fabsf(dz.z));
+        const float a = R0.x > R1.x ? R0.x : R1.x;
+        const float b = R0.y > R1.y ? R0.y : R1.y;
+        const float c = R0.z > R1.z ? R0.z : R1.z;
+        const float R_max = (a > b ? a : b) > c ? (a > b ? a : b) : c;
+        float s = (float)(0.84 * (double)sqrtf(sqrtf(tol / R_max)));        // :668 (powf -> two square roots)
+        if (R_max <= tol) {                                                 // accept the 4th-order result
+            pos = y4;
+            dir = (1 / refractive_index) * z4;
+            dir = normalize(dir);
+            rpos = pos;
+            rdir = dir;
+            mc.iterations++;
+            lookup = lookup_index(pos, v, scale);
+            if (!inside_box(pos, v, lookup)) return;
+            val = fetch(lookup);
+            refractive_index = val.w;                                       // :689 (n-1, as stored)
+            if ((double)s > 5.00) s = (float)5.00;
+            h *= s;
+        } else {
+            if ((double)s < 0.1) s = (float)0.1;
+            h *= s;
+        }
+    }
+}
+
+// adams_bashforth, .h:1293-1453: three RK4 start-up steps, then the 4-step Adams-Bashforth
+// predictor, on trilinear fetches of the raw volume.  Restated literally: .w (n-1) is used as the
+// refractive index throughout, the start-up loop tests ray_inside_box before its first step (so a ray
+// that enters through a max face is returned untouched), its retreat step is step/data_min, and the
+// main loop's retreat uses the position/direction captured before the loop.  Two definitions where
+// the reference has undefined behaviour or no bound: T_n_prev / D_n_prev / val are zero when the
+// start-up loop ends early (uninitialised there), and both loops are capped (LOOP_MAX, SPIN_MAX).
+void adams_bashforth(f3 &rpos, f3 &rdir, const Volume &v, f3 scale, MarchCount &mc) {
+    f3 pos = rpos, dir = rdir, lookup;
+    f4 val = f4{0, 0, 0, 0};
+    int loop_ctr = 0, spins = 0;
+    f3 R_n = mk3(0, 0, 0), T_n = mk3(0, 0, 0), A, B, C, D;
+    float delta_t;
+    f3 D_prev[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)}, T_prev[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+    auto fetch = [&](f3 l) { mc.samples++; return tex3d_linear(v, v.data, l.x, l.y, l.z); };
+    while (loop_ctr < 3) {                                              // :1316-1398
+        pos = rpos;
+        dir = rdir;
+        lookup = lookup_index(pos, v, scale);
+        if (!inside_box(pos, v, lookup)) break;
+        if (!can_access(v, lookup)) {
+            pos = pos + v.step_size / v.data_min * dir;
+            rpos = pos;
+            if (++spins > SPIN_MAX) break;
+            continue;
+        }
+        val = fetch(lookup);
+        if (val.w < v.data_min) {
+            pos = pos + v.step_size / v.data_min * dir;
+            rpos = pos;
+            if (++spins > SPIN_MAX) break;
+            continue;
+        }
+        R_n = pos;
+        delta_t = v.step_size / val.w;
+        T_n = val.w * rdir;
+        D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+        A = delta_t * D;
+        pos = R_n + (float)(delta_t / 2.0) * T_n + (float)(1 / 8.0 * delta_t) * A;
+        lookup = lookup_index(pos, v, scale);
+        if (!inside_box(pos, v, lookup)) break;
+        val = fetch(lookup);
+        D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+        B = delta_t * D;
+        pos = R_n + delta_t * T_n + (float)(1 / 2.0 * delta_t) * B;
+        lookup = lookup_index(pos, v, scale);
+        if (!inside_box(pos, v, lookup)) break;
+        val = fetch(lookup);
+        D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+        C = delta_t * D;
+        R_n = R_n + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));
+        T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);
+        rpos = R_n;
+        rdir = normalize(T_n / val.w);
+        T_prev[loop_ctr] = T_n;
+        D_prev[loop_ctr] = D;
+        loop_ctr += 1;
+        mc.iterations++;
+    }
+    loop_ctr = 0;                                                       // :1402-1450
+    const float refractive_index = val.w;
+    pos = rpos;
+    dir = rdir;
+    while (true) {
+        loop_ctr += 1;
+        if (loop_ctr > LOOP_MAX) break;
+        R_n = rpos;
+        lookup = lookup_index(R_n, v, scale);
+        if (!inside_box(R_n, v, lookup)) break;
+        val = fetch(lookup);
+        if (val.w < v.data_min) {
+            pos = pos + v.step_size / refractive_index * dir;
+            rpos = pos;
+            continue;
+        }
+        delta_t = v.step_size / val.w;
+        D = mk3(val.w * val.x, val.w * val.y, val.w * val.z);
+        const f3 R_n_1 = R_n + (delta_t / 24) * (55.0f * T_n - 59.0f * T_prev[2] + 37.0f * T_prev[1] - 9.0f * T_prev[0]);
+        const f3 T_n_1 = T_n + (delta_t / 24) * (55.0f * D - 59.0f * D_prev[2] + 37.0f * D_prev[1] - 9.0f * D_prev[0]);
+        T_prev[0] = T_prev[1]; D_prev[0] = D_prev[1];
+        T_prev[1] = T_prev[2]; D_prev[1] = D_prev[2];
+        T_prev[2] = T_n; D_prev[2] = D;
+        R_n = R_n_1;
+        T_n = T_n_1;
+        rpos = R_n;
+        rdir = normalize(T_n / val.w);
+        mc.iterations++;
+    }
+}
+
 // trace_rays_through_density_gradients, .h:1455-1544
 void trace_volume(f3 &pos_io, f3 &dir_io, const Volume &v, int algorithm, MarchCount &mc, const Noise &nz = Noise(),
                   uint64_t ray_id = 0, const InterRec *ir = nullptr) {
@@ -629,6 +834,8 @@ void trace_volume(f3 &pos_io, f3 &dir_io, const Volume &v, int algorithm, MarchC
     switch (algorithm) {
         case 1: euler(pos_io, dir_io, v, scale, mc, nz, ray_id, ir); break;
         case 2: rk4(pos_io, dir_io, v, scale, mc, ir); break;
+        case 3: rk45(pos_io, dir_io, v, scale, mc); break;
+        case 4: adams_bashforth(pos_io, dir_io, v, scale, mc); break;
         default: break;
     }
 }

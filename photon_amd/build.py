@@ -19,7 +19,7 @@ LIB_NAME = "libparallel_ray_tracing.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 
 SOURCES = [os.path.join(CSRC, "photon_core.hip")]
-HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp", "device_volume_coop.hpp", "device_optics.hpp")] + [
+HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp", "device_volume_coop.hpp", "device_volume_extra.hpp", "device_optics.hpp")] + [
     os.path.join(ROOT, "include", "parallel_ray_tracing.h"),
     os.path.join(ROOT, "include", "photon_det_math.h"),
     os.path.join(ROOT, "include", "photon_philox.h"),

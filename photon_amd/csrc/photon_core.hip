@@ -40,6 +40,7 @@
 #include "device_vec.hpp"
 #include "device_volume.hpp"
 #include "device_volume_coop.hpp"
+#include "device_volume_extra.hpp"
 
 using namespace photon;
 
@@ -232,6 +233,22 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
     }
 }
 
+// Algorithms 3 (rk45), 4 (adams_bashforth) and "anything else" (the reference's `default: break`,
+// .h:1537: the ray is only moved to its entry point): per-lane code, trilinear gathers of the raw volume.
+template <int ALGO>
+__global__ __launch_bounds__(256) void march_rays_extra_kernel(VolumeDev v, int n, float *__restrict__ pos,
+                                                               float *__restrict__ dir, int *__restrict__ steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 p = mk3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+    f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    MarchCount mc{0, 0};
+    trace_volume_extra<ALGO>(p, d, v, mc);
+    pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+    if (steps) steps[i] = mc.iterations;
+}
+
 // =============================================================================================
 // the two ray-tracing kernels
 // =============================================================================================
@@ -288,6 +305,23 @@ __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDe
         if (mc.iterations) atomicAdd(&counters[CNT_ITER], (unsigned long long)mc.iterations);
         if (mc.samples) atomicAdd(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
     }
+}
+
+// Stage 1b for ray_tracing_algorithm 3, 4 and the reference's no-op default (see march_rays_extra_kernel).
+template <int ALGO>
+__global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigned n_rays, RayStateDev st,
+                                                          unsigned long long *__restrict__ counters) {
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    MarchCount mc{0, 0};
+    if (r < n_rays) {
+        f3 p = mk3(st.px[r], st.py[r], st.pz[r]);
+        f3 d = mk3(st.dx[r], st.dy[r], st.dz[r]);
+        trace_volume_extra<ALGO>(p, d, vol, mc);
+        st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
+        st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+    }
+    wave_add(&counters[CNT_ITER], (unsigned long long)mc.iterations);
+    wave_add(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
 }
 
 // Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241).  FROM_STATE=false
@@ -604,9 +638,8 @@ int photon_volume_sample(const photon_volume_t *vol, int n, const float *coords,
 
 int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorithm, int n, float *pos, float *dir,
                              int *steps) {
-    if (!vol || n < 0 || (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2)) {
-        fprintf(stderr, "photon: photon_trace_volume_rays: unsupported algorithm %d (1 euler, 2 rk4)\n",
-                ray_tracing_algorithm);
+    if (!vol || n < 0) {
+        fprintf(stderr, "photon: photon_trace_volume_rays: bad arguments\n");
         return 1;
     }
     if (n == 0) return 0;
@@ -621,7 +654,10 @@ int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorit
     const dim3 grid((n + 255) / 256), block(256);
     const int interp = vol->dev.interpolation;
     const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
-    if (ray_tracing_algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_rays_kernel<1, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
+    if (ray_tracing_algorithm == 3) hipLaunchKernelGGL((march_rays_extra_kernel<3>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    else if (ray_tracing_algorithm == 4) hipLaunchKernelGGL((march_rays_extra_kernel<4>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    else if (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) hipLaunchKernelGGL((march_rays_extra_kernel<0>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
+    else if (ray_tracing_algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_rays_kernel<1, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
     else if (ray_tracing_algorithm == 1) hipLaunchKernelGGL((march_rays_kernel<1, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
     else if (interp == 1) hipLaunchKernelGGL((march_rays_kernel<2, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
     else hipLaunchKernelGGL((march_rays_kernel<2, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
@@ -782,7 +818,10 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
 #define PH_MARCH(A, I, S) hipLaunchKernelGGL((march_kernel<A, I, S>), grid, block, 0, stream, vol->dev, tex, n, s->ws, \
                                              s->d_counters, s->dev.noise, ray_base, idump)
-        if (algorithm == 1 && interp == 1) { if (save) PH_MARCH(1, 1, true); else PH_MARCH(1, 1, false); }
+        if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
+        else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
+        else if (algorithm != 1 && algorithm != 2) hipLaunchKernelGGL((march_extra_kernel<0>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
+        else if (algorithm == 1 && interp == 1) { if (save) PH_MARCH(1, 1, true); else PH_MARCH(1, 1, false); }
         else if (algorithm == 1) PH_MARCH(1, 2, false);
         else if (interp == 1) { if (save) PH_MARCH(2, 1, true); else PH_MARCH(2, 1, false); }
         else PH_MARCH(2, 2, false);
@@ -803,10 +842,6 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
     if (!scene || !d_image || src_begin < 0 || src_end < src_begin || src_end > scene->dev.num_sources) {
         fprintf(stderr, "photon: photon_trace: bad arguments (sources [%lld,%lld) of %d)\n", (long long)src_begin,
                 (long long)src_end, scene ? scene->dev.num_sources : -1);
-        return 1;
-    }
-    if (vol && ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) {
-        fprintf(stderr, "photon: ray_tracing_algorithm %d is not built (1 euler, 2 rk4)\n", ray_tracing_algorithm);
         return 1;
     }
     hipStream_t stream = (hipStream_t)stream_p;
@@ -923,11 +958,6 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
     const auto t0 = std::chrono::steady_clock::now();
     if (!image_array || !camera_design_p || !lightfield_source_p) {
         fprintf(stderr, "photon: start_ray_tracing: null argument; image left untouched\n");
-        return;
-    }
-    if (simulate_density_gradients && ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) {
-        fprintf(stderr, "photon: ray_tracing_algorithm %d (rk45 / adams-bashforth) is not built; image left untouched\n",
-                ray_tracing_algorithm);
         return;
     }
     photon_scene *scene = nullptr;

@@ -214,3 +214,36 @@ def test_intermediate_dumps_trace_the_march(oracle, tmp_path, algorithm):
     # cubic: nothing recorded
     oracle.render(call, interpolation=2)
     assert np.isnan(np.fromfile(tmp_path / "intermediate_pos_0000.bin", np.float32)).all()
+
+
+@pytest.mark.parametrize("algorithm", [3, 4])
+def test_rk45_and_adams_bashforth_go_straight_through_a_uniform_medium(oracle, algorithm):
+    """ray_tracing_algorithm 3 / 4 (.h:304-718, 1293-1453): with a zero gradient every stage leaves the
+    direction alone, so a ray started inside leaves through the far face on its straight line -- and a ray
+    that starts on a max face is returned untouched (both test ray_inside_box before the first step)."""
+    n = 24
+    rho = np.full((n, n, n), 1.225, np.float32)
+    vol = oracle.volume_from_density(rho, (100.0, 100.0, 100.0), (0.0, 0.0, 750e3), 1)
+    i = vol.info()
+    lo, hi = np.array(i.min_bound), np.array(i.max_bound)
+    rng = np.random.default_rng(5)
+    m = 200
+    pos = np.stack([rng.uniform(lo[a] + 300, hi[a] - 300, m) for a in range(3)], 1)
+    d = np.stack([rng.normal(0, 0.05, m), rng.normal(0, 0.05, m), np.ones(m)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p, dd, steps = vol.trace_rays(pos, d, algorithm)
+    assert steps.min() >= 1
+    np.testing.assert_allclose(dd, d, atol=2e-6)
+    t = ((p - pos) * d).sum(1)                                          # distance travelled along the ray
+    np.testing.assert_allclose(p, pos + t[:, None] * d, atol=0.05)      # still on its line
+    assert (t > 0).all()
+    if algorithm == 4:                                                  # fixed steps: it stops just outside the box
+        outside = (p < lo).any(1) | (p >= hi).any(1)
+        assert outside.all()
+    # from above, heading down: enters at z-max, stops there
+    pos2 = pos.copy()
+    pos2[:, 2] = hi[2] + 1000.0
+    d2 = d * np.array([1, 1, -1.0])
+    p2, dd2, steps2 = vol.trace_rays(pos2, d2, algorithm)
+    assert steps2.max() == 0 and np.array_equal(dd2, d2.astype(np.float32))
+    np.testing.assert_allclose(p2[:, 2], hi[2], rtol=1e-6)

@@ -127,6 +127,38 @@ def test_march_bit_exact(vol_pair, interp, algorithm):
     assert_bit_equal(gd, od, "marched directions")
 
 
+@pytest.mark.parametrize("algorithm", [3, 4, 0, 7])
+def test_other_integrators_bit_exact(vol_pair, algorithm):
+    """ray_tracing_algorithm 3 (rk45, .h:304-718), 4 (adams_bashforth, .h:1293-1453) and the reference's
+    `default: break` (.h:1537).  Both integrators fetch the raw volume trilinearly whatever the sampler;
+    rays that enter through a max face come back untouched (both test ray_inside_box before their first
+    step), so the test starts rays inside the volume and below it (entering through the z-min face)."""
+    for interp in (1, 2):
+        g, o = vol_pair[interp]
+        i = g.info()
+        rng = np.random.default_rng(17 + algorithm)
+        n = 3000
+        lo, hi = np.array(i.min_bound), np.array(i.max_bound)
+        pos = np.stack([rng.uniform(lo[a], hi[a], n) for a in range(3)], 1)            # inside
+        d = np.stack([rng.normal(0, 0.08, n), rng.normal(0, 0.08, n), np.ones(n)], 1)
+        pos[1000:2000, 2] = lo[2] - 3000.0                                             # below: enter at z-min, head up
+        pos[2000:, 2] = hi[2] + 3000.0                                                 # above: enter at z-max, head down
+        d[2000:, 2] = -1.0
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        gp, gd, gs = g.trace_rays(pos, d, algorithm)
+        op, od, os_ = o.trace_rays(pos, d, algorithm)
+        assert np.array_equal(gs, os_), "step counts differ"
+        assert_bit_equal(gp, op, f"algorithm {algorithm} positions")
+        assert_bit_equal(gd, od, f"algorithm {algorithm} directions")
+        if algorithm in (3, 4):
+            assert gs[:2000].max() > 10 and (gs[:2000] > 0).mean() > 0.9               # they really march ...
+            assert gs[2000:].max() == 0                                                # ... except from a max face
+            assert np.array_equal(gd[2000:], d[2000:].astype(np.float32))
+        else:
+            assert gs.max() == 0 and np.array_equal(gd, d.astype(np.float32))          # moved to the entry point only
+            assert np.array_equal(gp[:1000], pos[:1000].astype(np.float32))
+
+
 # ------------------------------------------------------------------------------------------------
 # full pipeline through start_ray_tracing
 # ------------------------------------------------------------------------------------------------
@@ -329,12 +361,23 @@ def test_gradient_noise_hook(photon, oracle, small_volume_file, monkeypatch):
     oracle.set_noise_seed(0)
 
 
+@pytest.mark.parametrize("algorithm", [3, 4, 9])
+def test_render_with_other_integrators(photon, oracle, small_volume_file, algorithm):
+    """The whole pipeline with ray_tracing_algorithm 3 / 4 / out-of-enum (reference: no-op default).  In the
+    BOS geometry every ray enters the volume through its z-max face, where rk45 and adams_bashforth stop
+    before their first step (as the reference's would): the image equals the no-op one, and the oracle's."""
+    call = scenes.bos_scene(n_dots=6, points_per_dot=20, rays_per_source=100, density_grad_filename=small_volume_file,
+                            ray_tracing_algorithm=algorithm)
+    g = photon.render(call)
+    o, _ = oracle.render(call)
+    assert g.any() and rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+    call.ray_tracing_algorithm = 0
+    assert np.array_equal(photon.render(call), g)
+
+
 def test_errors_leave_image_untouched(photon, small_volume_file, capfd):
     call = scenes.bos_scene(n_dots=2, points_per_dot=5, rays_per_source=8, density_grad_filename=small_volume_file)
     img = np.full(call.image_shape, 1.5, np.float32)
-    call.ray_tracing_algorithm = 3                     # rk45: not built
-    assert np.array_equal(photon.render(call, img.copy()), img)
-    call.ray_tracing_algorithm = 2
     call.density_grad_filename = "/nonexistent/volume.nrrd"
     assert np.array_equal(photon.render(call, img.copy()), img)
     assert "photon:" in capfd.readouterr().err
