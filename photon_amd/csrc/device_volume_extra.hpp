@@ -4,7 +4,7 @@
 // Per-lane code with per-lane trilinear gathers of the RAW gradient volume (the reference has no
 // cubic branch for them): these integrators are restated literally, oddities included -- .w (n-1)
 // used as the refractive index, the inside-box test before the very first step that turns both into
-// no-ops for rays entering through a max face (see oracle/photon_oracle.cpp for the list) -- so they
+// no-ops for rays entering through a max face (DESIGN.md section 5 has the list) -- so they
 // are about completing the enum and its wire behaviour, not about speed.  Operation order is that of
 // the C expressions in the reference (double literals fold to float factors before they meet a
 // float3); powf(x, 0.25f) is two correctly rounded square roots on both sides of the parity check.
