@@ -130,6 +130,9 @@ typedef struct camera_design_t {
  *   PHOTON_VERBOSE=1             progress / timing on stdout
  *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
  *                                reference seeds cuRAND with time(NULL); default 0x5eed)
+ *   PHOTON_DEVICES=all|0,1,..    shard the sources of one call over several GPUs (one host thread
+ *                                and one private image per device, summed at the end); default:
+ *                                the calling thread's current device
  */
 void start_ray_tracing(float lens_pitch, float image_distance,
                        scattering_data_t *scattering_data_p, char *scattering_type_str,

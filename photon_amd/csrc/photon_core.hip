@@ -30,9 +30,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/parallel_ray_tracing.h"
@@ -897,8 +899,9 @@ struct VolumeCache {                // the library stays loaded between photon's
     int device = -1;
     photon_volume *vol = nullptr;
 };
-std::mutex g_cache_mutex;
-VolumeCache g_cache;
+std::mutex g_cache_mutex;                       // guards the map; each entry has its own lock for the (slow) load
+struct DeviceCache { std::mutex lock; VolumeCache entry; };
+std::map<int, DeviceCache> g_cache;             // one cached volume per device (PHOTON_DEVICES renders on several)
 
 int interpolation_from_env() {
     const char *e = getenv("PHOTON_INTERP");
@@ -915,20 +918,54 @@ int cached_volume(const char *path, int interpolation, photon_volume **out) {
     int device = 0;
     (void)hipGetDevice(&device);
     const long long mt = (long long)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
-    std::lock_guard<std::mutex> lock(g_cache_mutex);
-    if (g_cache.vol && g_cache.path == path && g_cache.mtime_ns == mt && g_cache.size == (long long)st.st_size &&
-        g_cache.interpolation == interpolation && g_cache.device == device) {
-        *out = g_cache.vol;
+    DeviceCache *dc;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        dc = &g_cache[device];                  // std::map: references stay valid
+    }
+    std::lock_guard<std::mutex> lock(dc->lock);
+    VolumeCache &c = dc->entry;
+    if (c.vol && c.path == path && c.mtime_ns == mt && c.size == (long long)st.st_size && c.interpolation == interpolation) {
+        *out = c.vol;
         return 0;
     }
-    if (g_cache.vol) { photon_volume_free(g_cache.vol); g_cache.vol = nullptr; }
+    if (c.vol) { photon_volume_free(c.vol); c.vol = nullptr; }
     photon_volume *v = nullptr;
     const int rc = photon_volume_load_nrrd(path, interpolation, &v);
     if (rc) return rc;
-    g_cache.path = path; g_cache.mtime_ns = mt; g_cache.size = (long long)st.st_size;
-    g_cache.interpolation = interpolation; g_cache.device = device; g_cache.vol = v;
+    c.path = path; c.mtime_ns = mt; c.size = (long long)st.st_size;
+    c.interpolation = interpolation; c.device = device; c.vol = v;
     *out = v;
     return 0;
+}
+
+// PHOTON_DEVICES: "all", or a comma-separated list of device ordinals (repeats allowed: "0,0" renders two
+// shards side by side on device 0).  Empty = the calling thread's current device only.
+std::vector<int> devices_from_env() {
+    std::vector<int> out;
+    const char *e = getenv("PHOTON_DEVICES");
+    if (!e || !*e) return out;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return out;
+    if (strcmp(e, "all") == 0) {
+        for (int d = 0; d < count; d++) out.push_back(d);
+        return out;
+    }
+    const char *p = e;
+    while (*p) {
+        char *end = nullptr;
+        const long d = strtol(p, &end, 10);
+        if (end == p) break;
+        if (d < 0 || d >= count) {
+            fprintf(stderr, "photon: PHOTON_DEVICES names device %ld, %d present; using the current device\n", d, count);
+            out.clear();
+            return out;
+        }
+        out.push_back((int)d);
+        p = *end == ',' ? end + 1 : end;
+        if (*end && *end != ',') break;
+    }
+    return out;
 }
 
 bool write_dump(const char *dir, const char *prefix, int k, const std::vector<float> &v) {
@@ -959,6 +996,77 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
     if (!image_array || !camera_design_p || !lightfield_source_p) {
         fprintf(stderr, "photon: start_ray_tracing: null argument; image left untouched\n");
         return;
+    }
+    const bool dumping = save_lightrays && num_lightrays_save > 0;
+    {   // PHOTON_DEVICES: shard the sources over several GPUs inside this one call.  Ray dumps
+        // keep the reference's chunk -> file mapping and stay on one device.
+        const std::vector<int> devices = devices_from_env();
+        if (devices.size() > 1 && !dumping) {
+            const char *e = getenv("PHOTON_NOISE_SEED");
+            const uint64_t seed = e ? strtoull(e, nullptr, 0) : 0x5eedULL;
+            const long long n_src = lightfield_source_p->num_particles;
+            const size_t npix = (size_t)camera_design_p->x_pixel_number * camera_design_p->y_pixel_number;
+            const size_t K = devices.size();
+            std::vector<std::vector<float>> partial(K);
+            std::vector<int> rcs(K, 0);
+            std::vector<std::thread> workers;
+            for (size_t k = 0; k < K; k++) {
+                workers.emplace_back([&, k]() {
+                    // contiguous blocks of sources, balanced by count (all sources carry the same number of rays)
+                    const long long b = n_src * (long long)k / (long long)K, e2 = n_src * (long long)(k + 1) / (long long)K;
+                    rcs[k] = [&]() -> int {
+                        if (hipSetDevice(devices[k]) != hipSuccess) return 1;
+                        photon_scene *sc = nullptr;
+                        if (photon_scene_create(lens_pitch, image_distance, scattering_data_p, scattering_type_str,
+                                                lightfield_source_p, lightray_number_per_particle, beam_wavelength,
+                                                aperture_f_number, num_elements, element_center, element_data_p,
+                                                element_plane_parameters, element_system_index, camera_design_p,
+                                                ray_cone_pitch_ratio, &sc)) return 2;
+                        photon_scene_set_noise(sc, add_pos_noise, pos_noise_std, simulate_density_gradients && add_ngrad_noise,
+                                               ngrad_noise_std, seed);
+                        photon_volume *v = nullptr;
+                        float *d_img = nullptr;
+                        int rc = 0;
+                        if (simulate_density_gradients) rc = cached_volume(density_grad_filename, interpolation_from_env(), &v);
+                        if (!rc && hipMalloc((void **)&d_img, npix * sizeof(float)) != hipSuccess) rc = 3;
+                        if (!rc && hipMemset(d_img, 0, npix * sizeof(float)) != hipSuccess) rc = 3;
+                        if (!rc) rc = photon_trace(sc, v, ray_tracing_algorithm, b, e2, d_img, nullptr, nullptr);
+                        if (!rc && hipDeviceSynchronize() != hipSuccess) rc = 4;
+                        if (!rc) {
+                            partial[k].resize(npix);
+                            if (hipMemcpy(partial[k].data(), d_img, npix * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = 4;
+                        }
+                        if (d_img) (void)hipFree(d_img);
+                        photon_scene_free(sc);
+                        return rc;
+                    }();
+                });
+            }
+            for (auto &w : workers) w.join();
+            for (size_t k = 0; k < K; k++) {
+                if (rcs[k]) {
+                    fprintf(stderr, "photon: device %d failed (%d); image left untouched\n", devices[k], rcs[k]);
+                    return;
+                }
+            }
+            // the only shared state of the path is this sum: incoming image + the private images,
+            // added in device-list order in double, rounded once
+            for (size_t i = 0; i < npix; i++) {
+                double acc = (double)image_array[i];
+                for (size_t k = 0; k < K; k++) acc += (double)partial[k][i];
+                image_array[i] = (float)acc;
+            }
+            if (verbose()) {
+                const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                printf("photon: %lld sources x %d rays on %zu devices in %.3f s (%.2f Mrays/s incl. transfers)\n", n_src,
+                       lightray_number_per_particle, K, sec, n_src * (double)lightray_number_per_particle / sec * 1e-6);
+            }
+            return;
+        }
+        if (!devices.empty() && hipSetDevice(devices[0]) != hipSuccess) {
+            fprintf(stderr, "photon: cannot select device %d; image left untouched\n", devices[0]);
+            return;
+        }
     }
     photon_scene *scene = nullptr;
     float *d_image = nullptr, *d_fpos = nullptr, *d_fdir = nullptr, *d_ipos = nullptr, *d_idir = nullptr;
@@ -997,7 +1105,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
     const long long num_particles = lightfield_source_p->num_particles;
     const long long rps = lightray_number_per_particle;
     int rc = 0;
-    if (save_lightrays && num_lightrays_save > 0) {
+    if (dumping) {
         // the reference's chunking decides which rays land in which pos_/dir_ file (.cu:3366-3372,
         // 3515-3611): chunks of source_point_number sources, one file pair per chunk
         long long chunk = lightfield_source_p->source_point_number;

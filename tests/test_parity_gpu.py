@@ -375,6 +375,27 @@ def test_render_with_other_integrators(photon, oracle, small_volume_file, algori
     assert np.array_equal(photon.render(call), g)
 
 
+def test_in_library_device_sharding(photon, oracle, small_volume_file, monkeypatch):
+    """PHOTON_DEVICES: start_ray_tracing shards the sources over the listed devices (one host thread each,
+    private images, one sum at the end -- SURVEY 8e).  One GPU here, so the list repeats device 0: three
+    shards side by side must reproduce the single-pass image to the parity bar and keep accumulating on the
+    caller's image."""
+    call = scenes.bos_scene(n_dots=7, points_per_dot=20, rays_per_source=120, density_grad_filename=small_volume_file)
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    monkeypatch.delenv("PHOTON_DEVICES", raising=False)
+    single = photon.render(call)
+    monkeypatch.setenv("PHOTON_DEVICES", "0,0,0")
+    base = np.full(call.image_shape, 2.0, np.float32)
+    sharded = photon.render(call, base.copy())
+    assert rel_l2(sharded - base, single) <= IMAGE_TOL
+    o, _ = oracle.render(call, interpolation=2)
+    assert rel_l2(sharded - base, o) <= 2 * IMAGE_TOL           # (the +2.0 base costs a little f32 resolution)
+    monkeypatch.setenv("PHOTON_DEVICES", "all")                  # whatever the box has
+    assert rel_l2(photon.render(call), single) <= IMAGE_TOL
+    monkeypatch.setenv("PHOTON_DEVICES", "0,99")                 # a device that is not there: falls back, says so
+    assert rel_l2(photon.render(call), single) <= IMAGE_TOL
+
+
 def test_errors_leave_image_untouched(photon, small_volume_file, capfd):
     call = scenes.bos_scene(n_dots=2, points_per_dot=5, rays_per_source=8, density_grad_filename=small_volume_file)
     img = np.full(call.image_shape, 1.5, np.float32)
