@@ -130,6 +130,7 @@ typedef struct camera_design_t {
  *   PHOTON_VERBOSE=1             progress / timing on stdout
  *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
  *                                reference seeds cuRAND with time(NULL); default 0x5eed)
+ *   PHOTON_ELEMENT_TRAIN=reference|sequential   element-group walk (photon_scene_set_element_train)
  *   PHOTON_DEVICES=all|0,1,..    shard the sources of one call over several GPUs (one host thread
  *                                and one private image per device, summed at the end); default:
  *                                the calling thread's current device
@@ -228,6 +229,14 @@ void photon_scene_free(photon_scene_t *scene);
  * `seed` (include/photon_philox.h); off by default. */
 int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_noise_std, int add_ngrad_noise,
                            float ngrad_noise_std, uint64_t seed);
+
+/* How element groups are walked (propagate_rays_through_optical_system, parallel_ray_tracing.cu:1274-1381).
+ * mode 0 (default) = the reference as it runs: every single-member group goes through element 0
+ * (:1331-1333), groups of simultaneous elements reach an empty stub (:1049-1272).  mode 1 = the working
+ * train: each group through its own element(s), simultaneous elements (lenslet arrays, any number)
+ * chosen per ray by nearest centre on the element plane (design: perform_ray_tracing_03.py:1254-1485).
+ * start_ray_tracing reads it from PHOTON_ELEMENT_TRAIN=reference|sequential. */
+int photon_scene_set_element_train(photon_scene_t *scene, int mode);
 
 /* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.

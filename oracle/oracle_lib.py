@@ -96,6 +96,9 @@ class Oracle:
     def set_noise_seed(self, seed: int):
         self.lib.oracle_set_noise_seed(ctypes.c_uint64(int(seed)))
 
+    def set_element_train(self, mode: int):
+        self.lib.oracle_set_element_train(int(mode))
+
     def normal2(self, seed: int, n: int, draw: int = 0, stream: int = 1):
         out = np.empty((n, 2), np.float32)
         self.lib.oracle_normal2(ctypes.c_uint64(int(seed)), int(n), ctypes.c_uint32(draw), ctypes.c_uint32(stream), _p(out))

@@ -1017,17 +1017,81 @@ Ray single_element(const element_data_t &e, f3 center, const float plane[4], Ray
 // propagate_rays_through_optical_system, parallel_ray_tracing.cu:1274-1381.  Only the
 // single-element branch does anything in the reference (and it always uses element 0,
 // :1331-1333); groups with more than one simultaneous element reach a stub.
+//
+// train_mode 1 is the WORKING train the reference advertises, after the design of
+// its numpy ancestor (perform_ray_tracing_03.py:1254-1485; that code does not run either): groups in
+// decreasing system index; a single-member group goes through ITS element; a group of simultaneous
+// elements (a lenslet array) is split by element plane, the planes are visited in the order the ray
+// meets them, and on each plane the ray goes through the member whose centre is nearest to its
+// intersection point.  No reference output exists for this mode: it is pinned by optics (two thin
+// lenses in contact, tests/) and by GPU-vs-oracle parity only.
+int g_element_train = 0;            // oracle_set_element_train()
+
 Ray optical_system(const element_data_t *elems, const float (*centers)[3], const float (*planes)[4],
-                   const int *sys_index, int num_elements, Ray ray) {
+                   const int *sys_index, int num_elements, Ray ray, int train_mode = 0) {
     int seq = 0;
+    if (train_mode == 0) {
+        const int n = num_elements < 5 ? num_elements : 5;              // MAX_CURRENT_ELEMENTS, .cu:38
+        for (int k = 0; k < n; k++)
+            if (seq <= sys_index[k]) seq = sys_index[k];
+        for (int idx = 0; idx < seq; idx++) {
+            int count = 0;
+            for (int k = 0; k < n; k++)
+                if (seq - sys_index[k] == idx) count++;
+            if (count == 1)
+                ray = single_element(elems[0], mk3(centers[0][0], centers[0][1], centers[0][2]), planes[0], ray);
+        }
+        return ray;
+    }
+    auto same_plane = [](const float *p, const float *q) { return p[0] == q[0] && p[1] == q[1] && p[2] == q[2] && p[3] == q[3]; };
+    auto plane_time = [](const float *pl, const Ray &r) {
+        return -(pl[0] * r.pos.x + pl[1] * r.pos.y + pl[2] * r.pos.z + pl[3]) /
+               (pl[0] * r.dir.x + pl[1] * r.dir.y + pl[2] * r.dir.z);
+    };
     for (int k = 0; k < num_elements; k++)
         if (seq <= sys_index[k]) seq = sys_index[k];
     for (int idx = 0; idx < seq; idx++) {
-        int count = 0;
+        int count = 0, only = 0;
         for (int k = 0; k < num_elements; k++)
-            if (seq - sys_index[k] == idx) count++;
-        if (count == 1)
-            ray = single_element(elems[0], mk3(centers[0][0], centers[0][1], centers[0][2]), planes[0], ray);
+            if (seq - sys_index[k] == idx) { only = k; count++; }
+        if (count == 0) continue;
+        if (count == 1) {
+            ray = single_element(elems[only], mk3(centers[only][0], centers[only][1], centers[only][2]), planes[only], ray);
+            continue;
+        }
+        const int kMaxGroupPlanes = 8;
+        int uplane[kMaxGroupPlanes], nu = 0;
+        float ut[kMaxGroupPlanes];
+        for (int k = 0; k < num_elements; k++) {                        // distinct planes, first appearance first
+            if (seq - sys_index[k] != idx) continue;
+            bool seen = false;
+            for (int u = 0; u < nu; u++) seen = seen || same_plane(planes[uplane[u]], planes[k]);
+            if (seen || nu == kMaxGroupPlanes) continue;
+            uplane[nu] = k;
+            ut[nu] = plane_time(planes[k], ray);
+            nu++;
+        }
+        for (int a = 1; a < nu; a++) {                                  // stable insertion sort by time
+            const int pk = uplane[a];
+            const float tk = ut[a];
+            int b = a - 1;
+            while (b >= 0 && ut[b] > tk) { uplane[b + 1] = uplane[b]; ut[b + 1] = ut[b]; b--; }
+            uplane[b + 1] = pk; ut[b + 1] = tk;
+        }
+        for (int u = 0; u < nu; u++) {
+            const float *pl = planes[uplane[u]];
+            const float t = plane_time(pl, ray);
+            const f3 hit = ray.pos + t * ray.dir;
+            int best = -1;
+            float best_d2 = 0;
+            for (int k = 0; k < num_elements; k++) {
+                if (seq - sys_index[k] != idx || !same_plane(planes[k], pl)) continue;
+                const f3 dc = hit - mk3(centers[k][0], centers[k][1], centers[k][2]);
+                const float d2 = dot(dc, dc);
+                if (best < 0 || d2 < best_d2) { best = k; best_d2 = d2; }
+            }
+            ray = single_element(elems[best], mk3(centers[best][0], centers[best][1], centers[best][2]), planes[best], ray);
+        }
     }
     return ray;
 }
@@ -1212,7 +1276,7 @@ void trace_one(const Scene &sc, const Volume *vol, int algorithm, int64_t source
     }
     ray = optical_system(sc.elems.data(), reinterpret_cast<const float(*)[3]>(sc.centers.data()),
                          reinterpret_cast<const float(*)[4]>(sc.planes.data()), sc.sys_index.data(),
-                         sc.num_elements, ray);
+                         sc.num_elements, ray, g_element_train);
     if (isnan3(ray.dir) || isnan3(ray.pos)) return;                     // :2172-2176
     if (cam.implement_diffraction) {
         const f3 fin = sensor_diffraction(img, ray, cam, sc.noise, ray_id);
@@ -1525,6 +1589,7 @@ void oracle_det_eval(int fn, int n, const double *x, double *y) {
 }
 
 void oracle_set_noise_seed(uint64_t seed) { g_noise_seed = seed; }
+void oracle_set_element_train(int mode) { g_element_train = mode; }
 
 // include/photon_philox.h on the host: n pairs of N(0,1) for rays 0..n-1 (tests)
 void oracle_normal2(uint64_t seed, int n, uint32_t draw, uint32_t stream, float *out) {

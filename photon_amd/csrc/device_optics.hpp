@@ -47,6 +47,13 @@ struct SceneDev {
     float centers[kMaxElements][3];
     float planes[kMaxElements][4];
     int sys_index[kMaxElements];
+    // the working element train (train_mode 1): every element, in device memory (lenslet arrays have
+    // far more than kMaxElements members)
+    int train_mode;
+    const element_data_t *all_elems;
+    const float *all_centers;           // [num_elements][3]
+    const float *all_planes;            // [num_elements][4]
+    const int *all_sys_index;
     camera_design_t cam;
     NoiseDev noise;
 };
@@ -225,16 +232,85 @@ __device__ __forceinline__ Ray single_element(const element_data_t &e, f3 center
     return ray;
 }
 
+// The WORKING element train (train_mode 1; the reference advertises it, its device code is a stub and
+// its numpy ancestor perform_ray_tracing_03.py:1254-1485 does not run): groups in decreasing system
+// index; a single-member group goes through ITS element; a group of simultaneous elements (lenslet
+// array) is split by element plane, planes visited in the order the entering ray meets them, and on
+// each plane the ray goes through the member whose centre is nearest to its intersection point.
+constexpr int kMaxGroupPlanes = 8;
+__device__ __forceinline__ bool same_plane(const float *p, const float *q) {
+    return p[0] == q[0] && p[1] == q[1] && p[2] == q[2] && p[3] == q[3];
+}
+__device__ __forceinline__ float plane_time(const float *pl, const Ray &ray) {
+    return -(pl[0] * ray.pos.x + pl[1] * ray.pos.y + pl[2] * ray.pos.z + pl[3]) /
+           (pl[0] * ray.dir.x + pl[1] * ray.dir.y + pl[2] * ray.dir.z);
+}
+__device__ __noinline__ Ray element_train(const SceneDev &sc, Ray ray) {
+    const int n = sc.num_elements;
+    int seq = 0;
+    for (int k = 0; k < n; k++)
+        if (seq <= sc.all_sys_index[k]) seq = sc.all_sys_index[k];
+    for (int idx = 0; idx < seq; idx++) {
+        int count = 0, only = 0;
+        for (int k = 0; k < n; k++)
+            if (seq - sc.all_sys_index[k] == idx) { only = k; count++; }
+        if (count == 0) continue;
+        if (count == 1) {
+            const float *c = sc.all_centers + 3 * only;
+            ray = single_element(sc.all_elems[only], mk3(c[0], c[1], c[2]), sc.all_planes + 4 * only, ray);
+            continue;
+        }
+        int uplane[kMaxGroupPlanes], nu = 0;
+        float ut[kMaxGroupPlanes];
+        for (int k = 0; k < n; k++) {
+            if (seq - sc.all_sys_index[k] != idx) continue;
+            const float *pl = sc.all_planes + 4 * k;
+            bool seen = false;
+            for (int u = 0; u < nu; u++) seen = seen || same_plane(sc.all_planes + 4 * uplane[u], pl);
+            if (seen || nu == kMaxGroupPlanes) continue;
+            uplane[nu] = k;
+            ut[nu] = plane_time(pl, ray);
+            nu++;
+        }
+        for (int a = 1; a < nu; a++) {                                  // stable insertion sort by time
+            const int pk = uplane[a];
+            const float tk = ut[a];
+            int b = a - 1;
+            while (b >= 0 && ut[b] > tk) { uplane[b + 1] = uplane[b]; ut[b + 1] = ut[b]; b--; }
+            uplane[b + 1] = pk; ut[b + 1] = tk;
+        }
+        for (int u = 0; u < nu; u++) {
+            const float *pl = sc.all_planes + 4 * uplane[u];
+            const float t = plane_time(pl, ray);
+            const f3 hit = ray.pos + t * ray.dir;
+            int best = -1;
+            float best_d2 = 0;
+            for (int k = 0; k < n; k++) {
+                if (seq - sc.all_sys_index[k] != idx || !same_plane(sc.all_planes + 4 * k, pl)) continue;
+                const float *c = sc.all_centers + 3 * k;
+                const f3 dc = hit - mk3(c[0], c[1], c[2]);
+                const float d2 = dot(dc, dc);
+                if (best < 0 || d2 < best_d2) { best = k; best_d2 = d2; }
+            }
+            const float *c = sc.all_centers + 3 * best;
+            ray = single_element(sc.all_elems[best], mk3(c[0], c[1], c[2]), sc.all_planes + 4 * best, ray);
+        }
+    }
+    return ray;
+}
+
 // propagate_rays_through_optical_system (.cu:1274-1381): sequential groups; a group with exactly
 // one member is propagated through element 0 (.cu:1331-1333); larger groups reach the
 // reference's empty multi-element stub and leave the ray unchanged.
 __device__ __forceinline__ Ray optical_system(const SceneDev &sc, Ray ray) {
+    if (sc.train_mode != 0) return element_train(sc, ray);
     int seq = 0;
-    for (int k = 0; k < sc.num_elements; k++)
+    const int n = sc.num_elements < kMaxElements ? sc.num_elements : kMaxElements;
+    for (int k = 0; k < n; k++)
         if (seq <= sc.sys_index[k]) seq = sc.sys_index[k];
     for (int idx = 0; idx < seq; idx++) {
         int count = 0;
-        for (int k = 0; k < sc.num_elements; k++)
+        for (int k = 0; k < n; k++)
             if (seq - sc.sys_index[k] == idx) count++;
         if (count == 1)
             ray = single_element(sc.elems[0], mk3(sc.centers[0][0], sc.centers[0][1], sc.centers[0][2]),

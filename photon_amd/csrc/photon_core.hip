@@ -693,8 +693,8 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
         fprintf(stderr, "photon: photon_scene_create: null argument\n");
         return 1;
     }
-    if (num_elements < 1 || num_elements > kMaxElements) {
-        fprintf(stderr, "photon: %d optical elements given, 1..%d supported\n", num_elements, kMaxElements);
+    if (num_elements < 1 || num_elements > 65536) {
+        fprintf(stderr, "photon: %d optical elements given, 1..65536 supported\n", num_elements);
         return 1;
     }
     if (lightray_number_per_particle < 1 || lsp->num_particles < 0) {
@@ -734,11 +734,23 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
     if ((rc = upload(s, r1.data(), r1.size(), &d.r1))) return bail(rc);
     if ((rc = upload(s, r2.data(), r2.size(), &d.r2))) return bail(rc);
     d.num_elements = num_elements;
-    for (int k = 0; k < num_elements; k++) {                                   // .cu:3256-3260
-        d.elems[k] = edp[k];
-        for (int j = 0; j < 3; j++) d.centers[k][j] = (float)element_center[k][j];
-        for (int j = 0; j < 4; j++) d.planes[k][j] = (float)element_plane_parameters[k][j];
-        d.sys_index[k] = element_system_index[k];
+    {
+        std::vector<float> centers(3 * (size_t)num_elements), planes(4 * (size_t)num_elements);
+        for (int k = 0; k < num_elements; k++) {                               // .cu:3256-3260 (f64 -> f32)
+            for (int j = 0; j < 3; j++) centers[3 * k + j] = (float)element_center[k][j];
+            for (int j = 0; j < 4; j++) planes[4 * k + j] = (float)element_plane_parameters[k][j];
+            if (k < kMaxElements) {                                            // the reference path reads these
+                d.elems[k] = edp[k];
+                for (int j = 0; j < 3; j++) d.centers[k][j] = centers[3 * k + j];
+                for (int j = 0; j < 4; j++) d.planes[k][j] = planes[4 * k + j];
+                d.sys_index[k] = element_system_index[k];
+            }
+        }
+        d.train_mode = 0;
+        if ((rc = upload(s, edp, (size_t)num_elements, &d.all_elems))) return bail(rc);
+        if ((rc = upload(s, centers.data(), centers.size(), &d.all_centers))) return bail(rc);
+        if ((rc = upload(s, planes.data(), planes.size(), &d.all_planes))) return bail(rc);
+        if ((rc = upload(s, element_system_index, (size_t)num_elements, &d.all_sys_index))) return bail(rc);
     }
     d.cam = *cam;
     d.noise = NoiseDev{0, 0, 0.f, 0.f, 0ull};
@@ -763,6 +775,12 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
     if (!scene) return 1;
     scene->dev.noise = NoiseDev{add_pos_noise ? 1 : 0, add_ngrad_noise ? 1 : 0, pos_noise_std, ngrad_noise_std,
                                 (unsigned long long)seed};
+    return 0;
+}
+
+int photon_scene_set_element_train(photon_scene_t *s, int mode) {
+    if (!s || (mode != 0 && mode != 1)) return 1;
+    s->dev.train_mode = mode;
     return 0;
 }
 
@@ -909,6 +927,13 @@ int interpolation_from_env() {
     return 1;                       // the reference hard-codes interpolation_scheme = 1 (.cu:3330)
 }
 
+// PHOTON_ELEMENT_TRAIN=sequential: the working multi-element train instead of the reference's
+// "element 0 for every single-member group, nothing for the others" (.cu:1331-1333, 1049-1272)
+int element_train_from_env() {
+    const char *e = getenv("PHOTON_ELEMENT_TRAIN");
+    return e && (strcmp(e, "sequential") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
+}
+
 int cached_volume(const char *path, int interpolation, photon_volume **out) {
     struct stat st;
     if (stat(path, &st) != 0) {
@@ -1024,6 +1049,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                                                 ray_cone_pitch_ratio, &sc)) return 2;
                         photon_scene_set_noise(sc, add_pos_noise, pos_noise_std, simulate_density_gradients && add_ngrad_noise,
                                                ngrad_noise_std, seed);
+                        photon_scene_set_element_train(sc, element_train_from_env());
                         photon_volume *v = nullptr;
                         float *d_img = nullptr;
                         int rc = 0;
@@ -1092,6 +1118,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
         // gradient noise only exists inside the volume march (Euler, .h:853-863)
         photon_scene_set_noise(scene, add_pos_noise, pos_noise_std, simulate_density_gradients && add_ngrad_noise,
                                ngrad_noise_std, seed);
+        photon_scene_set_element_train(scene, element_train_from_env());
     }
     photon_volume *vol = nullptr;
     if (simulate_density_gradients) {

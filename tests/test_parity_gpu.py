@@ -375,6 +375,72 @@ def test_render_with_other_integrators(photon, oracle, small_volume_file, algori
     assert np.array_equal(photon.render(call), g)
 
 
+def _centroid(img):
+    yy, xx = np.mgrid[0:img.shape[0], 0:img.shape[1]]
+    w = img.astype(np.float64)
+    return np.array([(w * xx).sum(), (w * yy).sum()]) / w.sum()
+
+
+def test_element_train(photon, oracle, monkeypatch):
+    """The working multi-element train (PHOTON_ELEMENT_TRAIN=sequential / photon_scene_set_element_train;
+    the reference's device code for it is a stub, .cu:1049-1272, 1331-1333).  Pinned by optics -- two thin
+    lenses of focal length 2f in contact image like one of focal length f -- and by GPU-vs-oracle parity,
+    including a group of simultaneous elements (two lenslets side by side: rays pick the nearer one)."""
+    import copy
+    single = scenes.bos_scene(n_dots=5, points_per_dot=20, rays_per_source=100, lens_model="thin-lens", seed=4)
+    ref_img = photon.render(single)
+    # doublet: same place, half the power each, system indices 2 (hit first) and 1
+    doublet = copy.deepcopy(single)
+    e = copy.deepcopy(single.elements[0])
+    e["element_properties"]["thin_lens_focal_length"] *= 2.0
+    doublet.elements = [e, copy.deepcopy(e)]
+    doublet.element_center = np.repeat(single.element_center, 2, axis=0)
+    doublet.element_plane_parameters = np.repeat(single.element_plane_parameters, 2, axis=0)
+    doublet.element_system_index = np.array([2, 1], np.int32)
+    monkeypatch.setenv("PHOTON_ELEMENT_TRAIN", "sequential")
+    oracle.set_element_train(1)
+    try:
+        g = photon.render(doublet)
+        o, st = oracle.render(doublet)
+        assert st.rays_on_sensor > 0
+        assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+        assert np.abs(_centroid(g) - _centroid(ref_img)).max() < 0.05       # pixels
+        assert rel_l2(g, ref_img) < 0.05
+        # lenslet pair: two thin lenses side by side on one plane, one system index
+        pair = copy.deepcopy(single)
+        pitch = single.elements[0]["element_geometry"]["pitch"]
+        half = copy.deepcopy(single.elements[0])
+        half["element_geometry"]["pitch"] = pitch / 2.0
+        pair.elements = [half, copy.deepcopy(half)]
+        c = single.element_center[0]
+        pair.element_center = np.array([[c[0] - pitch / 4.0, c[1], c[2]], [c[0] + pitch / 4.0, c[1], c[2]]])
+        pair.element_plane_parameters = np.repeat(single.element_plane_parameters, 2, axis=0)
+        pair.element_system_index = np.array([1, 1], np.int32)
+        g2 = photon.render(pair)
+        o2, st2 = oracle.render(pair)
+        assert 0 < st2.rays_on_sensor < pair.num_rays                          # lenslet apertures clip rays
+        assert rel_l2(g2, o2) <= IMAGE_TOL, rel_l2(g2, o2)
+        assert rel_l2(g2, ref_img) > 0.1                                       # two displaced images, not one
+        # the device-resident API takes the same switch
+        import torch
+        scene = photon.scene_create(pair)
+        scene.set_element_train(1)
+        img = torch.zeros(pair.image_shape[0] * pair.image_shape[1], dtype=torch.float32, device="cuda")
+        scene.trace(img.data_ptr())
+        assert rel_l2(img.cpu().numpy().reshape(pair.image_shape), g2) <= IMAGE_TOL
+        scene.free()
+    finally:
+        oracle.set_element_train(0)
+    # default = the reference as it runs: element 0 for every single-member group, nothing for larger groups
+    monkeypatch.delenv("PHOTON_ELEMENT_TRAIN")
+    g3 = photon.render(doublet)
+    o3, _ = oracle.render(doublet)
+    assert rel_l2(g3, o3) <= IMAGE_TOL if o3.any() else not g3.any()
+    g4 = photon.render(pair)                                                   # one group of two: the stub, rays pass straight
+    o4, _ = oracle.render(pair)
+    assert rel_l2(g4, o4) <= IMAGE_TOL if o4.any() else not g4.any()
+
+
 def test_in_library_device_sharding(photon, oracle, small_volume_file, monkeypatch):
     """PHOTON_DEVICES: start_ray_tracing shards the sources over the listed devices (one host thread each,
     private images, one sum at the end -- SURVEY 8e).  One GPU here, so the list repeats device 0: three
