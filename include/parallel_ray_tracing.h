@@ -252,6 +252,60 @@ int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_trac
 int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorithm, int n,
                              float *pos, float *dir, int *steps);
 
+/* ------------------------------------------------------------------------------------
+ * Section 3: scene generation on the device (the step right before the
+ * hot path).  photon builds its source arrays and its synthetic density files in Python
+ * (run_simulation_02.py, nrrd_functions.py) and ships them through start_ray_tracing; for
+ * 1e6-source / 512^3 configurations these entry points build the same data directly in HBM.
+ * ---------------------------------------------------------------------------------- */
+
+typedef struct photon_sources photon_sources_t; /* light-field sources (x, y, z, radiance, diameter index) in HBM */
+
+/* BOS target, generate_bos_lightfield_data (run_simulation_02.py:1328-1551): every dot centre
+ * (dot_x[g], dot_y[g]) is expanded by the point template (tmpl_x[j], tmpl_y[j]) -- the sunflower
+ * disc of calculate_sunflower_coordinates (:999-1056) -- into source g*n_tmpl + j at
+ * (dot_x[g] + tmpl_x[j], dot_y[g] + tmpl_y[j], z); sums in double, stored as f32 (what the ctypes
+ * marshalling does, perform_ray_tracing_03.py:1730-1745); radiance constant, diameter index 1. */
+int photon_sources_bos(const double *dot_x, const double *dot_y, int n_dots, const double *tmpl_x,
+                       const double *tmpl_y, int n_tmpl, double z, double radiance,
+                       photon_sources_t **out);
+/* PIV particle field, run_simulation_02.py:774-996: X, Y, Z uniform in [box_min, box_max),
+ * radiance = irradiance_constant / (sigma sqrt(2 pi)) * exp(-Z^2 / (2 sigma^2)) with
+ * sigma = beam_fwhm / (2 sqrt(2 ln 2)) (the laser sheet, :961-962), z = Z + z_object.  The reference
+ * draws from numpy's unseeded generator; here particle i takes the four 32-bit words of
+ * Philox4x32-10(seed, i) (include/photon_philox.h, stream PHOTON_STREAM_SCENE): reproducible, and any
+ * particle can be regenerated on its own.  diameter_cdf (may be NULL): cumulative distribution over
+ * n_diameters table columns, index = first d with u < cdf[d]; NULL = index 1 like the reference (:992). */
+int photon_sources_piv(uint64_t seed, long long n, const double box_min[3], const double box_max[3],
+                       double z_object, double beam_fwhm, double irradiance_constant,
+                       const double *diameter_cdf, int n_diameters, photon_sources_t **out);
+long long photon_sources_count(const photon_sources_t *sources);
+/* Copy back to host arrays (any of them may be NULL). */
+int photon_sources_download(const photon_sources_t *sources, float *x, float *y, float *z, double *radiance,
+                            int *diameter_index);
+void photon_sources_free(photon_sources_t *sources);
+
+/* photon_scene_create with the sources taken from `sources` (device-to-device copy; the scene does not
+ * keep a reference).  lightfield_source_p supplies the scalars only (z_offset, object_distance,
+ * source_point_number): its arrays and num_particles are ignored. */
+int photon_scene_create_from_sources(float lens_pitch, float image_distance,
+                                     const scattering_data_t *scattering_data_p, const char *scattering_type_str,
+                                     const lightfield_source_t *lightfield_source_p,
+                                     const photon_sources_t *sources, int lightray_number_per_particle,
+                                     float beam_wavelength, float aperture_f_number, int num_elements,
+                                     const double (*element_center)[3], const element_data_t *element_data_p,
+                                     const double (*element_plane_parameters)[4], const int *element_system_index,
+                                     const camera_design_t *camera_design_p, float ray_cone_pitch_ratio,
+                                     photon_scene_t **out);
+
+/* Synthetic density field evaluated on the device instead of written to / read from an NRRD file
+ * (nrrd_functions.py:14-57 is the writer it replaces): rho = rho0 + amp * exp(-|r - centre|^2 / (2 sigma^2))
+ * on the grid origin + i * spacing, then the same volume build as photon_volume_load_nrrd.  origin is the
+ * NRRD "space origin" (before the -750e3 z shift), centre in the same frame. */
+int photon_volume_gaussian(int nx, int ny, int nz, const double spacing[3], const double origin[3],
+                           double rho0, double amp, const double centre[3], double sigma,
+                           int interpolation, photon_volume_t **out);
+
 /* Library / build identification string (static storage). */
 const char *photon_version(void);
 

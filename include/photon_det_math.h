@@ -135,6 +135,44 @@ PHOTON_HD double photon_det_acos(double x) {
 }
 
 /* float-in / float-out forms: evaluate in double, round once. */
+/* exp(x), used by the on-device scene generators (laser-sheet profile, synthetic density fields):
+ * x = k ln2 + r with |r| <= ln2/2 (Cody-Waite, ln2 split so that k*LN2_HI is exact for |k| < 2^20),
+ * exp(r) by its Taylor series to r^14/14! (truncation < 2e-19 relative), scaled by 2^k through the
+ * exponent field.  Underflows to 0 below -708, overflows to +inf above 709; NaN propagates. */
+#define PHOTON_LN2_HI 6.93147180369123816490e-01
+#define PHOTON_LN2_LO 1.90821492927058770002e-10
+#define PHOTON_1_LN2  1.44269504088896338700e+00
+PHOTON_HD double photon_det_exp(double x) {
+    if (x != x) return x;
+    if (x > 709.0) return 1.0 / 0.0;
+    if (x < -708.0) return 0.0;
+    const double k = rint(x * PHOTON_1_LN2);
+    double r = fma(-k, PHOTON_LN2_HI, x);
+    r = fma(-k, PHOTON_LN2_LO, r);
+    double p = 1.0 / 87178291200.0;                         /* 1/14! */
+    p = fma(p, r, 1.0 / 6227020800.0);                     /* 1/13! */
+    p = fma(p, r, 1.0 / 479001600.0);                      /* 1/12! */
+    p = fma(p, r, 1.0 / 39916800.0);                       /* 1/11! */
+    p = fma(p, r, 1.0 / 3628800.0);                        /* 1/10! */
+    p = fma(p, r, 1.0 / 362880.0);                         /* 1/9!  */
+    p = fma(p, r, 1.0 / 40320.0);                          /* 1/8!  */
+    p = fma(p, r, 1.0 / 5040.0);                           /* 1/7!  */
+    p = fma(p, r, 1.0 / 720.0);                            /* 1/6!  */
+    p = fma(p, r, 1.0 / 120.0);                            /* 1/5!  */
+    p = fma(p, r, 1.0 / 24.0);                             /* 1/4!  */
+    p = fma(p, r, 1.0 / 6.0);                              /* 1/3!  */
+    p = fma(p, r, 0.5);                                    /* 1/2!  */
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    /* 2^k: two factors so that the scaling itself never over/underflows prematurely */
+    const long long ki = (long long)k;
+    const long long k1 = ki / 2, k2 = ki - k1;
+    union { unsigned long long u; double d; } a, b;
+    a.u = (unsigned long long)(k1 + 1023) << 52;
+    b.u = (unsigned long long)(k2 + 1023) << 52;
+    return p * a.d * b.d;
+}
+
 PHOTON_HD float photon_det_atanf(float x) { return (float)photon_det_atan((double)x); }
 PHOTON_HD float photon_det_tanf(float x) { return (float)photon_det_tan((double)x); }
 PHOTON_HD float photon_det_acosf(float x) { return (float)photon_det_acos((double)x); }

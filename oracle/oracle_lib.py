@@ -127,6 +127,43 @@ class Oracle:
         h = self.lib.oracle_volume_from_density(_p(rho), nx, ny, nz, _p(sp), _p(og), interpolation, tex_frac_bits)
         return OracleVolume(self, h)
 
+    def volume_gaussian(self, n, spacing, origin, rho0, amp, centre, sigma, interpolation=1, tex_frac_bits=0):
+        nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+        sp = np.ascontiguousarray(np.broadcast_to(np.asarray(spacing, np.float64), (3,)))
+        og = np.ascontiguousarray(origin, dtype=np.float64)
+        c = np.ascontiguousarray(centre, dtype=np.float64)
+        self.lib.oracle_volume_gaussian.restype = ctypes.c_void_p
+        h = self.lib.oracle_volume_gaussian(int(nx), int(ny), int(nz), _p(sp), _p(og), ctypes.c_double(rho0),
+                                            ctypes.c_double(amp), _p(c), ctypes.c_double(sigma), int(interpolation),
+                                            int(tex_frac_bits))
+        return OracleVolume(self, h)
+
+    # ---- scene generation -----------------------------------------------------------------
+    def sources_bos(self, dot_xy, template_xy, z, radiance):
+        d = np.ascontiguousarray(dot_xy, dtype=np.float64).reshape(-1, 2)
+        t = np.ascontiguousarray(template_xy, dtype=np.float64).reshape(-1, 2)
+        dx, dy, tx, ty = (np.ascontiguousarray(a) for a in (d[:, 0], d[:, 1], t[:, 0], t[:, 1]))
+        n = d.shape[0] * t.shape[0]
+        out = dict(x=np.empty(n, np.float32), y=np.empty(n, np.float32), z=np.empty(n, np.float32),
+                   radiance=np.empty(n, np.float64), diameter_index=np.empty(n, np.int32))
+        self.lib.oracle_sources_bos(_p(dx), _p(dy), d.shape[0], _p(tx), _p(ty), t.shape[0], ctypes.c_double(z),
+                                    ctypes.c_double(radiance), _p(out["x"]), _p(out["y"]), _p(out["z"]),
+                                    _p(out["radiance"]), _p(out["diameter_index"]))
+        return out
+
+    def sources_piv(self, seed, n, box_min, box_max, z_object, beam_fwhm, irradiance_constant, diameter_cdf=None):
+        lo = np.ascontiguousarray(box_min, dtype=np.float64)
+        hi = np.ascontiguousarray(box_max, dtype=np.float64)
+        cdf = None if diameter_cdf is None else np.ascontiguousarray(diameter_cdf, dtype=np.float64)
+        out = dict(x=np.empty(n, np.float32), y=np.empty(n, np.float32), z=np.empty(n, np.float32),
+                   radiance=np.empty(n, np.float64), diameter_index=np.empty(n, np.int32))
+        self.lib.oracle_sources_piv(ctypes.c_uint64(int(seed)), ctypes.c_longlong(int(n)), _p(lo), _p(hi),
+                                    ctypes.c_double(z_object), ctypes.c_double(beam_fwhm),
+                                    ctypes.c_double(irradiance_constant), _p(cdf) if cdf is not None else None,
+                                    0 if cdf is None else int(cdf.size), _p(out["x"]), _p(out["y"]), _p(out["z"]),
+                                    _p(out["radiance"]), _p(out["diameter_index"]))
+        return out
+
     def volume_load_nrrd(self, path, interpolation=1, tex_frac_bits=0):
         h = self.lib.oracle_volume_load_nrrd(path.encode(), interpolation, tex_frac_bits)
         assert h, f"oracle could not read {path}"

@@ -1588,6 +1588,70 @@ void oracle_det_eval(int fn, int n, const double *x, double *y) {
     }
 }
 
+// ---- scene generation (the product's Section 3 entry points, restated on the CPU) -----------
+// BOS target: generate_bos_lightfield_data, run_simulation_02.py:1328-1551 (x = dot + template, in double,
+// stored f32 by the ctypes marshalling).
+void oracle_sources_bos(const double *dot_x, const double *dot_y, int n_dots, const double *tx, const double *ty,
+                        int n_tmpl, double z, double radiance, float *x, float *y, float *zz, double *rad, int *dia) {
+    for (long long g = 0; g < n_dots; g++)
+        for (int j = 0; j < n_tmpl; j++) {
+            const long long i = g * n_tmpl + j;
+            x[i] = (float)(dot_x[g] + tx[j]);
+            y[i] = (float)(dot_y[g] + ty[j]);
+            zz[i] = (float)z;
+            rad[i] = radiance;
+            dia[i] = 1;
+        }
+}
+// PIV particle field: run_simulation_02.py:774-996 with Philox(seed, i) in place of numpy's unseeded generator.
+void oracle_sources_piv(uint64_t seed, long long n, const double lo[3], const double hi[3], double z_object,
+                        double beam_fwhm, double irradiance_constant, const double *cdf, int n_diameters, float *x,
+                        float *y, float *z, double *rad, int *dia) {
+    const double sigma = beam_fwhm / (2.0 * sqrt(2.0 * log(2.0)));     // :961
+    const double coef = irradiance_constant * (1.0 / (sigma * sqrt(2.0 * PHOTON_PI)));
+    const double two_sigma2 = 2.0 * (sigma * sigma);
+    for (long long i = 0; i < n; i++) {
+        const photon_u32x4 r = photon_philox4x32_10(seed, (uint64_t)i, 0u, PHOTON_STREAM_SCENE);
+        const double ux = ((double)r.x + 0.5) * (1.0 / 4294967296.0), uy = ((double)r.y + 0.5) * (1.0 / 4294967296.0);
+        const double uz = ((double)r.z + 0.5) * (1.0 / 4294967296.0), ud = ((double)r.w + 0.5) * (1.0 / 4294967296.0);
+        const double X = (hi[0] - lo[0]) * ux + lo[0];                  // :949-951
+        const double Y = (hi[1] - lo[1]) * uy + lo[1];
+        const double Z = (hi[2] - lo[2]) * uz + lo[2];
+        x[i] = (float)X;
+        y[i] = (float)Y;
+        z[i] = (float)(Z + z_object);                                   // :965
+        rad[i] = coef * photon_det_exp(-1.0 * (Z * Z / two_sigma2));    // :962
+        int d = 1;                                                      // :992
+        if (n_diameters > 0) {
+            d = n_diameters - 1;
+            for (int q = 0; q < n_diameters; q++)
+                if (ud < cdf[q]) { d = q; break; }
+        }
+        dia[i] = d;
+    }
+}
+// Synthetic Gaussian density field -> volume (what nrrd_functions.py:14-57 would write and loadNRRD read back).
+void *oracle_volume_gaussian(int nx, int ny, int nz, const double spacing[3], const double origin[3], double rho0,
+                             double amp, const double centre[3], double sigma, int interpolation, int tex_frac_bits) {
+    const int dims[3] = {nx, ny, nz};
+    std::vector<double> prof[3];
+    for (int a = 0; a < 3; a++) {
+        prof[a].resize(dims[a]);
+        for (int i = 0; i < dims[a]; i++) {
+            const double x = origin[a] + spacing[a] * (double)i;
+            prof[a][i] = photon_det_exp(-((x - centre[a]) * (x - centre[a])) / (2 * (sigma * sigma)));
+        }
+    }
+    std::vector<float> rho((size_t)nx * ny * nz);
+    for (int k = 0; k < nz; k++)
+        for (int j = 0; j < ny; j++)
+            for (int i = 0; i < nx; i++)
+                rho[((size_t)k * ny + j) * nx + i] = (float)(rho0 + amp * prof[2][k] * (prof[1][j] * prof[0][i]));
+    Volume *v = new Volume();
+    setup_volume(*v, rho.data(), nx, ny, nz, spacing, origin, interpolation, tex_frac_bits);
+    return v;
+}
+
 void oracle_set_noise_seed(uint64_t seed) { g_noise_seed = seed; }
 void oracle_set_element_train(int mode) { g_element_train = mode; }
 

@@ -163,6 +163,67 @@ __global__ __launch_bounds__(256) void build_volume_kernel(const float *__restri
     if (threadIdx.x == 0) block_min[blockIdx.x] = red[0];
 }
 
+// rho[k][j][i] = rho0 + amp * gz[k] * (gy[j] * gx[i]) in double, rounded once to f32 (the order of the
+// numpy expression a host-side generator would use): the density of photon_volume_gaussian.
+__global__ __launch_bounds__(256) void separable_density_kernel(const double *__restrict__ gx, const double *__restrict__ gy,
+                                                                const double *__restrict__ gz, int W, int H, int D, double rho0,
+                                                                double amp, float *__restrict__ rho) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)W * H * D) return;
+    const int i = (int)(idx % W), j = (int)((idx / W) % H), k = (int)(idx / ((size_t)W * H));
+    rho[idx] = (float)(rho0 + amp * gz[k] * (gy[j] * gx[i]));
+}
+
+// Light-field sources generated in HBM.
+// BOS target (generate_bos_lightfield_data, run_simulation_02.py:1328-1551): source (dot g, point j) sits at
+// (dot_x[g] + tmpl_x[j], dot_y[g] + tmpl_y[j], z); sums in double, cast to f32 like the ctypes marshalling.
+__global__ __launch_bounds__(256) void sources_bos_kernel(const double *__restrict__ dot_x, const double *__restrict__ dot_y,
+                                                          long long n_dots, const double *__restrict__ tx,
+                                                          const double *__restrict__ ty, int n_tmpl, double z, double radiance,
+                                                          float *sx, float *sy, float *sz, double *srad, int *sdia) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dots * n_tmpl) return;
+    const long long g = i / n_tmpl;
+    const int j = (int)(i % n_tmpl);
+    sx[i] = (float)(dot_x[g] + tx[j]);
+    sy[i] = (float)(dot_y[g] + ty[j]);
+    sz[i] = (float)z;
+    srad[i] = radiance;
+    sdia[i] = 1;                                                        // run_simulation_02.py:1544
+}
+
+// PIV particle field (run_simulation_02.py:774-996): X, Y, Z uniform in the box, radiance = the laser
+// sheet's Gaussian profile in Z, Z shifted to the object plane.  The reference draws from numpy's unseeded
+// generator; here particle i takes the four words of Philox(seed, i) -- any particle can be regenerated.
+struct PivFieldDev {
+    double lo[3], hi[3];
+    double z_object, coef, two_sigma2;      // coef = irradiance_constant / (sigma sqrt(2 pi))
+    int n_diameters;                        // 0: diameter_index = 1 (run_simulation_02.py:992)
+};
+__global__ __launch_bounds__(256) void sources_piv_kernel(unsigned long long seed, long long n, PivFieldDev f,
+                                                          const double *__restrict__ diameter_cdf, float *sx, float *sy,
+                                                          float *sz, double *srad, int *sdia) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const photon_u32x4 r = photon_philox4x32_10(seed, (unsigned long long)i, 0u, PHOTON_STREAM_SCENE);
+    const double ux = ((double)r.x + 0.5) * (1.0 / 4294967296.0), uy = ((double)r.y + 0.5) * (1.0 / 4294967296.0);
+    const double uz = ((double)r.z + 0.5) * (1.0 / 4294967296.0), ud = ((double)r.w + 0.5) * (1.0 / 4294967296.0);
+    const double X = (f.hi[0] - f.lo[0]) * ux + f.lo[0];
+    const double Y = (f.hi[1] - f.lo[1]) * uy + f.lo[1];
+    const double Z = (f.hi[2] - f.lo[2]) * uz + f.lo[2];
+    sx[i] = (float)X;
+    sy[i] = (float)Y;
+    sz[i] = (float)(Z + f.z_object);
+    srad[i] = f.coef * photon_det_exp(-1.0 * (Z * Z / f.two_sigma2));
+    int dia = 1;
+    if (f.n_diameters > 0) {
+        dia = f.n_diameters - 1;
+        for (int d = 0; d < f.n_diameters; d++)
+            if (ud < diameter_cdf[d]) { dia = d; break; }
+    }
+    sdia[i] = dia;
+}
+
 // ConvertToInterpolationCoefficients (cubicPrefilter_kernel.cu:52-112) on all four channels of one
 // line of float4 texels, in place.  One thread per line; `lines_inner` lines are adjacent in
 // memory by `inner_stride` texels (coalesced for the y and z passes).
@@ -411,6 +472,13 @@ struct photon_volume {
     f4 *d_coeffs = nullptr;
 };
 
+struct photon_sources {                 // light-field sources generated in HBM (SoA, like lightfield_source_t)
+    long long n = 0;
+    float *x = nullptr, *y = nullptr, *z = nullptr;
+    double *radiance = nullptr;
+    int *diameter_index = nullptr;
+};
+
 struct photon_scene {
     SceneDev dev{};
     std::vector<void *> allocs;         // device buffers owned by the scene
@@ -428,6 +496,16 @@ static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
     PH_CHECK(hipMalloc((void **)&d, bytes));
     s->allocs.push_back(d);
     if (n) PH_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = d;
+    return 0;
+}
+
+template <typename T>
+static int copy_device(photon_scene *s, const T *dev_src, size_t n, const T **dev_out) {
+    T *d = nullptr;
+    PH_CHECK(hipMalloc((void **)&d, std::max<size_t>(n, 1) * sizeof(T)));
+    s->allocs.push_back(d);
+    if (n) PH_CHECK(hipMemcpy(d, dev_src, n * sizeof(T), hipMemcpyDeviceToDevice));
     *dev_out = d;
     return 0;
 }
@@ -526,10 +604,67 @@ void photon_volume_free(photon_volume_t *vol) {
     delete vol;
 }
 
+// Where the density comes from: a host array (NRRD / caller) or a field evaluated on the device
+// (photon_volume_gaussian): rho0 + amp * gz[k] * (gy[j] * gx[i]) from three device-resident axis profiles.
+struct DensitySource {
+    const float *host_rho = nullptr;
+    const double *d_gx = nullptr, *d_gy = nullptr, *d_gz = nullptr;
+    double rho0 = 0, amp = 0;
+};
+
+static int volume_build(const DensitySource &src, int nx, int ny, int nz, const double spacing[3],
+                        const double origin[3], int interpolation, photon_volume_t **out);
+
 int photon_volume_from_density(const float *rho, int nx, int ny, int nz, const double spacing[3],
                                const double origin[3], int interpolation, photon_volume_t **out) {
-    if (!rho || !out || nx < 3 || ny < 3 || nz < 3 || (interpolation != 1 && interpolation != 2)) {
+    if (!rho) {
         fprintf(stderr, "photon: photon_volume_from_density: bad arguments\n");
+        return 1;
+    }
+    DensitySource src;
+    src.host_rho = rho;
+    return volume_build(src, nx, ny, nz, spacing, origin, interpolation, out);
+}
+
+// Synthetic density field evaluated on the device: rho = rho0 + amp * exp(-|r - centre|^2 / (2 sigma^2)),
+// separable, so the host prepares three axis profiles (O(n) work, photon_det_exp) and a kernel fills the
+// n^3 grid in HBM -- no host array, no file, no upload (BASELINE C3 / C4's volume).
+int photon_volume_gaussian(int nx, int ny, int nz, const double spacing[3], const double origin[3], double rho0,
+                           double amp, const double centre[3], double sigma, int interpolation,
+                           photon_volume_t **out) {
+    if (!spacing || !origin || !centre || !(sigma > 0) || nx < 3 || ny < 3 || nz < 3) {
+        fprintf(stderr, "photon: photon_volume_gaussian: bad arguments\n");
+        return 1;
+    }
+    const int dims[3] = {nx, ny, nz};
+    std::vector<double> prof[3];
+    double *d_prof[3] = {nullptr, nullptr, nullptr};
+    int rc = 0;
+    for (int a = 0; a < 3 && !rc; a++) {
+        prof[a].resize(dims[a]);
+        for (int i = 0; i < dims[a]; i++) {
+            const double x = origin[a] + spacing[a] * (double)i;
+            prof[a][i] = photon_det_exp(-((x - centre[a]) * (x - centre[a])) / (2 * (sigma * sigma)));
+        }
+        if (hipMalloc((void **)&d_prof[a], dims[a] * sizeof(double)) != hipSuccess ||
+            hipMemcpy(d_prof[a], prof[a].data(), dims[a] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = 3;
+    }
+    if (!rc) {
+        DensitySource src;
+        src.d_gx = d_prof[0]; src.d_gy = d_prof[1]; src.d_gz = d_prof[2];
+        src.rho0 = rho0; src.amp = amp;
+        rc = volume_build(src, nx, ny, nz, spacing, origin, interpolation, out);
+    } else {
+        fprintf(stderr, "photon: photon_volume_gaussian: device allocation failed\n");
+    }
+    for (double *p : d_prof) if (p) (void)hipFree(p);
+    return rc;
+}
+
+static int volume_build(const DensitySource &src, int nx, int ny, int nz, const double spacing[3],
+                        const double origin[3], int interpolation, photon_volume_t **out) {
+    if (!out || !spacing || !origin || nx < 3 || ny < 3 || nz < 3 || (interpolation != 1 && interpolation != 2)) {
+        fprintf(stderr, "photon: volume: bad arguments\n");
         return 1;
     }
     // bounds from the file's own size (loadNRRD, .h:1696-1706), then the 1024-slice cap (.h:1714-1717)
@@ -550,7 +685,13 @@ int photon_volume_from_density(const float *rho, int nx, int ny, int nz, const d
     PH_VCHECK(hipMalloc((void **)&v->d_texels, n * sizeof(f4)));
     PH_VCHECK(hipMalloc((void **)&d_rho, n * sizeof(float)));
     PH_VCHECK(hipMalloc((void **)&d_min, blocks * sizeof(float)));
-    PH_VCHECK(hipMemcpy(d_rho, rho, n * sizeof(float), hipMemcpyHostToDevice));
+    if (src.host_rho) {
+        PH_VCHECK(hipMemcpy(d_rho, src.host_rho, n * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        hipLaunchKernelGGL(separable_density_kernel, dim3(blocks), dim3(256), 0, 0, src.d_gx, src.d_gy, src.d_gz, nx, ny, nz,
+                           src.rho0, src.amp, d_rho);
+        PH_VCHECK(hipGetLastError());
+    }
     const float gx = (float)spacing[0], gy = (float)spacing[1], gz = (float)spacing[2];
     hipLaunchKernelGGL(build_volume_kernel, dim3(blocks), dim3(256), 0, 0, d_rho, nx, ny, nz, gx, gy, gz, v->d_texels,
                        d_min);
@@ -682,12 +823,156 @@ void photon_scene_free(photon_scene_t *s) {
     delete s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// light-field sources generated on the device
+// ---------------------------------------------------------------------------------------------
+void photon_sources_free(photon_sources_t *src) {
+    if (!src) return;
+    if (src->x) (void)hipFree(src->x);
+    if (src->y) (void)hipFree(src->y);
+    if (src->z) (void)hipFree(src->z);
+    if (src->radiance) (void)hipFree(src->radiance);
+    if (src->diameter_index) (void)hipFree(src->diameter_index);
+    delete src;
+}
+
+static int sources_alloc(long long n, photon_sources **out) {
+    photon_sources *src = new photon_sources();
+    src->n = n;
+    const size_t m = (size_t)std::max<long long>(n, 1);
+    if (hipMalloc((void **)&src->x, m * sizeof(float)) != hipSuccess || hipMalloc((void **)&src->y, m * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&src->z, m * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&src->radiance, m * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&src->diameter_index, m * sizeof(int)) != hipSuccess) {
+        fprintf(stderr, "photon: sources: device allocation failed\n");
+        photon_sources_free(src);
+        return 3;
+    }
+    *out = src;
+    return 0;
+}
+
+int photon_sources_bos(const double *dot_x, const double *dot_y, int n_dots, const double *tmpl_x, const double *tmpl_y,
+                       int n_tmpl, double z, double radiance, photon_sources_t **out) {
+    if (!out || n_dots < 0 || n_tmpl < 1 || (n_dots && (!dot_x || !dot_y)) || !tmpl_x || !tmpl_y ||
+        (long long)n_dots * n_tmpl > 0x7fffffffLL) {
+        fprintf(stderr, "photon: photon_sources_bos: bad arguments\n");
+        return 1;
+    }
+    const long long n = (long long)n_dots * n_tmpl;
+    photon_sources *src = nullptr;
+    int rc = sources_alloc(n, &src);
+    if (rc) return rc;
+    double *d_in = nullptr;                                             // dot_x | dot_y | tmpl_x | tmpl_y
+    const size_t total = 2 * (size_t)n_dots + 2 * (size_t)n_tmpl;
+    auto fail = [&](int code) { if (d_in) (void)hipFree(d_in); photon_sources_free(src); return code; };
+    if (hipMalloc((void **)&d_in, total * sizeof(double)) != hipSuccess) return fail(3);
+    double *d_dx = d_in, *d_dy = d_in + n_dots, *d_tx = d_in + 2 * (size_t)n_dots, *d_ty = d_tx + n_tmpl;
+    if ((n_dots && (hipMemcpy(d_dx, dot_x, n_dots * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(d_dy, dot_y, n_dots * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) ||
+        hipMemcpy(d_tx, tmpl_x, n_tmpl * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ty, tmpl_y, n_tmpl * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(4);
+    if (n) {
+        hipLaunchKernelGGL(sources_bos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_dx, d_dy, (long long)n_dots,
+                           d_tx, d_ty, n_tmpl, z, radiance, src->x, src->y, src->z, src->radiance, src->diameter_index);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(4);
+    }
+    (void)hipFree(d_in);
+    *out = src;
+    return 0;
+}
+
+int photon_sources_piv(uint64_t seed, long long n, const double box_min[3], const double box_max[3], double z_object,
+                       double beam_fwhm, double irradiance_constant, const double *diameter_cdf, int n_diameters,
+                       photon_sources_t **out) {
+    if (!out || n < 0 || n > 0x7fffffffLL || !box_min || !box_max || !(beam_fwhm > 0) || n_diameters < 0 ||
+        (n_diameters > 0 && !diameter_cdf)) {
+        fprintf(stderr, "photon: photon_sources_piv: bad arguments\n");
+        return 1;
+    }
+    photon_sources *src = nullptr;
+    int rc = sources_alloc(n, &src);
+    if (rc) return rc;
+    PivFieldDev f;
+    for (int a = 0; a < 3; a++) { f.lo[a] = box_min[a]; f.hi[a] = box_max[a]; }
+    const double sigma = beam_fwhm / (2.0 * sqrt(2.0 * log(2.0)));     // run_simulation_02.py:961
+    f.z_object = z_object;
+    f.coef = irradiance_constant * (1.0 / (sigma * sqrt(2.0 * PHOTON_PI)));
+    f.two_sigma2 = 2.0 * (sigma * sigma);
+    f.n_diameters = n_diameters;
+    double *d_cdf = nullptr;
+    auto fail = [&](int code) { if (d_cdf) (void)hipFree(d_cdf); photon_sources_free(src); return code; };
+    if (n_diameters > 0) {
+        if (hipMalloc((void **)&d_cdf, n_diameters * sizeof(double)) != hipSuccess) return fail(3);
+        if (hipMemcpy(d_cdf, diameter_cdf, n_diameters * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(4);
+    }
+    if (n) {
+        hipLaunchKernelGGL(sources_piv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (unsigned long long)seed, n, f,
+                           d_cdf, src->x, src->y, src->z, src->radiance, src->diameter_index);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(4);
+    }
+    if (d_cdf) (void)hipFree(d_cdf);
+    *out = src;
+    return 0;
+}
+
+long long photon_sources_count(const photon_sources_t *src) { return src ? src->n : -1; }
+
+int photon_sources_download(const photon_sources_t *src, float *x, float *y, float *z, double *radiance,
+                            int *diameter_index) {
+    if (!src) return 1;
+    const size_t n = (size_t)src->n;
+    if (!n) return 0;
+    if (x) PH_CHECK(hipMemcpy(x, src->x, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (y) PH_CHECK(hipMemcpy(y, src->y, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (z) PH_CHECK(hipMemcpy(z, src->z, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (radiance) PH_CHECK(hipMemcpy(radiance, src->radiance, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (diameter_index) PH_CHECK(hipMemcpy(diameter_index, src->diameter_index, n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int scene_create_impl(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                             const char *scattering_type_str, const lightfield_source_t *lsp,
+                             const photon_sources *generated, int lightray_number_per_particle, float beam_wavelength,
+                             float aperture_f_number, int num_elements, const double (*element_center)[3],
+                             const element_data_t *edp, const double (*element_plane_parameters)[4],
+                             const int *element_system_index, const camera_design_t *cam, float ray_cone_pitch_ratio,
+                             photon_scene_t **out);
+
 int photon_scene_create(float lens_pitch, float image_distance, const scattering_data_t *sdp,
                         const char *scattering_type_str, const lightfield_source_t *lsp,
                         int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
                         int num_elements, const double (*element_center)[3], const element_data_t *edp,
                         const double (*element_plane_parameters)[4], const int *element_system_index,
                         const camera_design_t *cam, float ray_cone_pitch_ratio, photon_scene_t **out) {
+    return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, nullptr,
+                             lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                             edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+}
+
+int photon_scene_create_from_sources(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                                     const char *scattering_type_str, const lightfield_source_t *lsp,
+                                     const photon_sources_t *sources, int lightray_number_per_particle,
+                                     float beam_wavelength, float aperture_f_number, int num_elements,
+                                     const double (*element_center)[3], const element_data_t *edp,
+                                     const double (*element_plane_parameters)[4], const int *element_system_index,
+                                     const camera_design_t *cam, float ray_cone_pitch_ratio, photon_scene_t **out) {
+    if (!sources) {
+        fprintf(stderr, "photon: photon_scene_create_from_sources: null sources\n");
+        return 1;
+    }
+    return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, sources,
+                             lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                             edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+}
+
+static int scene_create_impl(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                             const char *scattering_type_str, const lightfield_source_t *lsp,
+                             const photon_sources *generated, int lightray_number_per_particle, float beam_wavelength,
+                             float aperture_f_number, int num_elements, const double (*element_center)[3],
+                             const element_data_t *edp, const double (*element_plane_parameters)[4],
+                             const int *element_system_index, const camera_design_t *cam, float ray_cone_pitch_ratio,
+                             photon_scene_t **out) {
     if (!sdp || !scattering_type_str || !lsp || !edp || !cam || !out || !element_center || !element_plane_parameters ||
         !element_system_index) {
         fprintf(stderr, "photon: photon_scene_create: null argument\n");
@@ -697,7 +982,8 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
         fprintf(stderr, "photon: %d optical elements given, 1..65536 supported\n", num_elements);
         return 1;
     }
-    if (lightray_number_per_particle < 1 || lsp->num_particles < 0) {
+    const long long n_sources = generated ? generated->n : (long long)lsp->num_particles;
+    if (lightray_number_per_particle < 1 || n_sources < 0 || n_sources > 0x7fffffffLL) {
         fprintf(stderr, "photon: bad ray / source counts\n");
         return 1;
     }
@@ -709,13 +995,21 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
     d.f_number = aperture_f_number; d.ratio = ray_cone_pitch_ratio;
     d.scattering_type = strcmp(scattering_type_str, "mie") == 0 ? 1 : 0;       // .cu:3192
     d.rays_per_source = lightray_number_per_particle;
-    const size_t ns = (size_t)lsp->num_particles;
+    const size_t ns = (size_t)n_sources;
     d.num_sources = (int)ns;
-    if ((rc = upload(s, lsp->x, ns, &d.sx))) return bail(rc);
-    if ((rc = upload(s, lsp->y, ns, &d.sy))) return bail(rc);
-    if ((rc = upload(s, lsp->z, ns, &d.sz))) return bail(rc);
-    if ((rc = upload(s, lsp->radiance, ns, &d.sradiance))) return bail(rc);
-    if ((rc = upload(s, lsp->diameter_index, ns, &d.sdia))) return bail(rc);
+    if (generated) {                                    // already in HBM: device-to-device, no host arrays
+        if ((rc = copy_device<float>(s, generated->x, ns, &d.sx))) return bail(rc);
+        if ((rc = copy_device<float>(s, generated->y, ns, &d.sy))) return bail(rc);
+        if ((rc = copy_device<float>(s, generated->z, ns, &d.sz))) return bail(rc);
+        if ((rc = copy_device<double>(s, generated->radiance, ns, &d.sradiance))) return bail(rc);
+        if ((rc = copy_device<int>(s, generated->diameter_index, ns, &d.sdia))) return bail(rc);
+    } else {
+        if ((rc = upload(s, lsp->x, ns, &d.sx))) return bail(rc);
+        if ((rc = upload(s, lsp->y, ns, &d.sy))) return bail(rc);
+        if ((rc = upload(s, lsp->z, ns, &d.sz))) return bail(rc);
+        if ((rc = upload(s, lsp->radiance, ns, &d.sradiance))) return bail(rc);
+        if ((rc = upload(s, lsp->diameter_index, ns, &d.sdia))) return bail(rc);
+    }
     d.z_offset = lsp->z_offset; d.object_distance = lsp->object_distance;
     memcpy(d.mie_inv_rot, sdp->inverse_rotation_matrix, sizeof d.mie_inv_rot);
     memcpy(d.beam, sdp->beam_propagation_vector, sizeof d.beam);

@@ -22,6 +22,9 @@ DECLARED_SYMBOLS = (
     "photon_volume_from_density", "photon_volume_info", "photon_volume_download", "photon_volume_sample",
     "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_trace",
     "photon_trace_volume_rays", "photon_version",
+    # section 3: scene generation on the device
+    "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
+    "photon_scene_create_from_sources", "photon_volume_gaussian",
 )
 
 
@@ -88,6 +91,21 @@ class PhotonLibrary:
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(photon_trace_stats_t)]
         L.photon_trace_volume_rays.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p]
+        L.photon_sources_bos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]
+        L.photon_sources_piv.argtypes = [ctypes.c_uint64, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_void_p)]
+        L.photon_sources_count.argtypes = [ctypes.c_void_p]
+        L.photon_sources_count.restype = ctypes.c_longlong
+        L.photon_sources_download.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
+        L.photon_sources_free.argtypes = [ctypes.c_void_p]
+        L.photon_sources_free.restype = None
+        L.photon_scene_create_from_sources.argtypes = (L.photon_scene_create.argtypes[:5] + [ctypes.c_void_p] +
+                                                       L.photon_scene_create.argtypes[5:])
+        L.photon_volume_gaussian.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
+                                             ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
 
     # ---- helpers --------------------------------------------------------------------------
     @staticmethod
@@ -133,7 +151,57 @@ class PhotonLibrary:
                                                         ctypes.byref(h)), "photon_volume_from_density")
         return Volume(self, h)
 
+    def volume_gaussian(self, n, spacing, origin, rho0: float, amp: float, centre, sigma: float,
+                        interpolation: int = 1) -> "Volume":
+        """rho0 + amp exp(-|r - centre|^2 / 2 sigma^2) evaluated on the device (no host array, no file)."""
+        nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+        sp = np.ascontiguousarray(np.broadcast_to(np.asarray(spacing, np.float64), (3,)))
+        og = np.ascontiguousarray(origin, dtype=np.float64)
+        c = np.ascontiguousarray(centre, dtype=np.float64)
+        h = ctypes.c_void_p()
+        self._check(self.lib.photon_volume_gaussian(int(nx), int(ny), int(nz), _ptr(sp), _ptr(og), float(rho0), float(amp),
+                                                    _ptr(c), float(sigma), int(interpolation), ctypes.byref(h)),
+                    "photon_volume_gaussian")
+        return Volume(self, h)
+
+    # ---- sources generated on the device ------------------------------------------------------
+    def sources_bos(self, dot_xy, template_xy, z: float, radiance: float) -> "Sources":
+        d = np.ascontiguousarray(dot_xy, dtype=np.float64).reshape(-1, 2)
+        t = np.ascontiguousarray(template_xy, dtype=np.float64).reshape(-1, 2)
+        dx, dy, tx, ty = (np.ascontiguousarray(a) for a in (d[:, 0], d[:, 1], t[:, 0], t[:, 1]))
+        h = ctypes.c_void_p()
+        self._check(self.lib.photon_sources_bos(_ptr(dx), _ptr(dy), d.shape[0], _ptr(tx), _ptr(ty), t.shape[0], float(z),
+                                                float(radiance), ctypes.byref(h)), "photon_sources_bos")
+        return Sources(self, h)
+
+    def sources_piv(self, seed: int, n: int, box_min, box_max, z_object: float, beam_fwhm: float,
+                    irradiance_constant: float, diameter_cdf=None) -> "Sources":
+        lo = np.ascontiguousarray(box_min, dtype=np.float64)
+        hi = np.ascontiguousarray(box_max, dtype=np.float64)
+        cdf = None if diameter_cdf is None else np.ascontiguousarray(diameter_cdf, dtype=np.float64)
+        h = ctypes.c_void_p()
+        self._check(self.lib.photon_sources_piv(int(seed), int(n), _ptr(lo), _ptr(hi), float(z_object), float(beam_fwhm),
+                                                float(irradiance_constant), _ptr(cdf) if cdf is not None else None,
+                                                0 if cdf is None else int(cdf.size), ctypes.byref(h)),
+                    "photon_sources_piv")
+        return Sources(self, h)
+
     # ---- scenes -------------------------------------------------------------------------------
+    def scene_create_from_sources(self, call: RayTracingCall, sources: "Sources") -> "Scene":
+        """Like scene_create, with the light-field sources already in HBM (call's own source arrays unused)."""
+        sd, ls, elems, centers, planes, sysidx, cam = call.pack()
+        h = ctypes.c_void_p()
+        rc = self.lib.photon_scene_create_from_sources(
+            ctypes.c_float(call.lens_pitch), ctypes.c_float(call.image_distance), ctypes.byref(sd),
+            call.scattering_type.encode(), ctypes.byref(ls), sources.handle, int(call.lightray_number_per_particle),
+            ctypes.c_float(call.beam_wavelength), ctypes.c_float(call.aperture_f_number), len(call.elements),
+            _ptr(centers), elems, _ptr(planes), _ptr(sysidx), ctypes.byref(cam),
+            ctypes.c_float(call.ray_cone_pitch_ratio), ctypes.byref(h))
+        self._check(rc, "photon_scene_create_from_sources")
+        scene = Scene(self, h, call)
+        scene.num_sources = sources.count()
+        return scene
+
     def scene_create(self, call: RayTracingCall) -> "Scene":
         sd, ls, elems, centers, planes, sysidx, cam = call.pack()
         h = ctypes.c_void_p()
@@ -184,15 +252,40 @@ class Volume:
             self.handle = None
 
 
+class Sources:
+    """Light-field sources generated in HBM (photon_sources_t)."""
+
+    def __init__(self, lib: PhotonLibrary, handle):
+        self._lib, self.handle = lib, handle
+
+    def count(self) -> int:
+        return int(self._lib.lib.photon_sources_count(self.handle))
+
+    def download(self) -> dict:
+        n = self.count()
+        out = dict(x=np.empty(n, np.float32), y=np.empty(n, np.float32), z=np.empty(n, np.float32),
+                   radiance=np.empty(n, np.float64), diameter_index=np.empty(n, np.int32))
+        self._lib._check(self._lib.lib.photon_sources_download(self.handle, _ptr(out["x"]), _ptr(out["y"]), _ptr(out["z"]),
+                                                               _ptr(out["radiance"]), _ptr(out["diameter_index"])),
+                         "photon_sources_download")
+        return out
+
+    def free(self):
+        if self.handle:
+            self._lib.lib.photon_sources_free(self.handle)
+            self.handle = None
+
+
 class Scene:
     def __init__(self, lib: PhotonLibrary, handle, call: RayTracingCall):
         self._lib, self.handle, self.call = lib, handle, call
+        self.num_sources = call.num_sources
 
     def trace(self, d_image_ptr: int, volume: Optional[Volume] = None, algorithm: int = 0, src_begin: int = 0,
               src_end: Optional[int] = None, stream: int = 0, want_stats: bool = False):
         """Accumulate into a DEVICE image (raw pointer, e.g. torch tensor .data_ptr())."""
         if src_end is None:
-            src_end = self.call.num_sources
+            src_end = self.num_sources
         stats = photon_trace_stats_t() if want_stats else None
         rc = self._lib.lib.photon_trace(self.handle, volume.handle if volume is not None else None, int(algorithm),
                                         int(src_begin), int(src_end), ctypes.c_void_p(int(d_image_ptr)),

@@ -120,15 +120,21 @@ def _call(cam_geom, camera, **kw) -> RayTracingCall:
         element_system_index=cam_geom["element_system_index"], camera=camera, source_point_number=10000, **kw)
 
 
+def bos_pattern(n_dots: int = 200, points_per_dot: int = 100, field_half_width: float = 3.0e4,
+                dot_diameter: float = 600.0, seed: int = 1):
+    """Dot centres [n_dots, 2] and the per-dot point template [points_per_dot, 2] of bos_scene: the inputs of the
+    on-device generator photon_sources_bos (source g*P + j = centre g + template j)."""
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-field_half_width, field_half_width, size=(n_dots, 2)), sunflower_disc(points_per_dot, dot_diameter)
+
+
 def bos_scene(n_dots: int = 200, points_per_dot: int = 100, rays_per_source: int = 500,
               density_grad_filename: str = "", field_half_width: float = 3.0e4, dot_diameter: float = 600.0,
               seed: int = 1, lens_model: str = "general", n_pixels: int = 1024,
               ray_tracing_algorithm: int = 2) -> RayTracingCall:
     """C3 / C4: dot pattern at the object plane, diffuse sources, erf splat (D = 3 px)."""
     geom = single_lens_camera(lens_model=lens_model, **SAMPLE_LENS)
-    rng = np.random.default_rng(seed)
-    centres = rng.uniform(-field_half_width, field_half_width, size=(n_dots, 2))
-    disc = sunflower_disc(points_per_dot, dot_diameter)
+    centres, disc = bos_pattern(n_dots, points_per_dot, field_half_width, dot_diameter, seed)
     xy = (centres[:, None, :] + disc[None, :, :]).reshape(-1, 2)
     n = xy.shape[0]
     return _call(geom, sample_camera(True, n_pixels), scattering_type="diffuse",

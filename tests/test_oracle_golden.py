@@ -247,3 +247,49 @@ def test_rk45_and_adams_bashforth_go_straight_through_a_uniform_medium(oracle, a
     p2, dd2, steps2 = vol.trace_rays(pos2, d2, algorithm)
     assert steps2.max() == 0 and np.array_equal(dd2, d2.astype(np.float32))
     np.testing.assert_allclose(p2[:, 2], hi[2], rtol=1e-6)
+
+
+def test_scene_generators_against_numpy(oracle):
+    """The CPU restatement of the on-device scene generators (include/parallel_ray_tracing.h section 3):
+    BOS sources = what scenes.bos_scene builds with numpy, bit for bit; the PIV field is uniform in its box with
+    the laser sheet's Gaussian radiance (run_simulation_02.py:949-965); the Gaussian volume = the numpy field."""
+    from photon_amd import scenes
+    centres, disc = scenes.bos_pattern(n_dots=13, points_per_dot=37, seed=6)
+    call = scenes.bos_scene(n_dots=13, points_per_dot=37, seed=6)
+    z_obj = float(call.src_z[0])
+    s = oracle.sources_bos(centres, disc, z_obj, 10.0)
+    assert np.array_equal(s["x"], call.src_x.astype(np.float32)) and np.array_equal(s["y"], call.src_y.astype(np.float32))
+    assert np.array_equal(s["z"], call.src_z.astype(np.float32)) and np.all(s["radiance"] == 10.0)
+    assert np.all(s["diameter_index"] == 1)
+    # PIV field
+    lo, hi = (-7.5e4, -7.5e4, -7.5e3), (7.5e4, 7.5e4, 7.5e3)
+    n = 200_000
+    p = oracle.sources_piv(42, n, lo, hi, z_obj, 730.0, 500.0)
+    for a, key in enumerate("xy"):
+        assert lo[a] <= p[key].min() and p[key].max() <= hi[a]
+        assert abs(p[key].mean()) < 3 * (hi[a] - lo[a]) / np.sqrt(12 * n) * 1.5
+        assert abs(p[key].std() - (hi[a] - lo[a]) / np.sqrt(12)) < 0.01 * (hi[a] - lo[a])
+    Z = p["z"].astype(np.float64) - z_obj
+    sigma = 730.0 / (2.0 * np.sqrt(2.0 * np.log(2.0)))
+    expect = 500.0 / (sigma * np.sqrt(2 * np.pi)) * np.exp(-Z ** 2 / (2 * sigma ** 2))
+    # z is stored in f32 at ~8e5 um (ulp 0.0625 um): compare where that rounding does not dominate
+    core = np.abs(Z) < 2 * sigma
+    np.testing.assert_allclose(p["radiance"][core], expect[core], rtol=2e-3)
+    assert np.all(p["diameter_index"] == 1)
+    assert not np.array_equal(p["x"], oracle.sources_piv(43, n, lo, hi, z_obj, 730.0, 500.0)["x"])      # keyed by seed
+    q = oracle.sources_piv(42, 1000, lo, hi, z_obj, 730.0, 500.0)                                        # counter-based: a prefix
+    assert np.array_equal(q["x"], p["x"][:1000]) and np.array_equal(q["radiance"], p["radiance"][:1000])
+    cdf = np.cumsum([0.1, 0.2, 0.3, 0.4])
+    d = oracle.sources_piv(42, n, lo, hi, z_obj, 730.0, 500.0, diameter_cdf=cdf)["diameter_index"]
+    np.testing.assert_allclose(np.bincount(d, minlength=4) / n, [0.1, 0.2, 0.3, 0.4], atol=5e-3)
+    # Gaussian volume
+    nvol = 24
+    rho, sp, org = scenes.bos_volume(nvol)
+    centre = [org[a] + sp[a] * (nvol - 1) / 2.0 for a in range(3)]
+    sigma_v = 8.0e3
+    vg = oracle.volume_gaussian(nvol, sp, org, 1.225, 0.2, centre, sigma_v, 1)
+    vn = oracle.volume_from_density(rho, sp, org, 1)
+    a, b = vg.download(), vn.download()
+    np.testing.assert_allclose(a[..., 3], b[..., 3], rtol=3e-7)         # n-1: exp implementations differ by <= 1 ulp (f64)
+    assert np.abs(a[..., :3] - b[..., :3]).max() <= 1e-3 * np.abs(b[..., :3]).max()
+    assert vg.info().step_size == vn.info().step_size and list(vg.info().min_bound) == list(vn.info().min_bound)

@@ -375,6 +375,71 @@ def test_render_with_other_integrators(photon, oracle, small_volume_file, algori
     assert np.array_equal(photon.render(call), g)
 
 
+def test_scene_generation_on_device(photon, oracle, monkeypatch):
+    """include/parallel_ray_tracing.h section 3: BOS and PIV sources and the synthetic
+    Gaussian volume built in HBM are bit-identical to the CPU restatement (and, for BOS, to the numpy arrays the
+    host path uploads), and a scene created from them renders the same image as one created from host arrays."""
+    import torch
+    centres, disc = scenes.bos_pattern(n_dots=9, points_per_dot=31, seed=8)
+    rho, sp, org = scenes.bos_volume(40)
+    centre = [org[a] + sp[a] * (40 - 1) / 2.0 for a in range(3)]
+    call = scenes.bos_scene(n_dots=9, points_per_dot=31, rays_per_source=90, seed=8)
+    z_obj = float(call.src_z[0])
+    # --- BOS sources
+    src = photon.sources_bos(centres, disc, z_obj, 10.0)
+    assert src.count() == call.num_sources
+    got, want = src.download(), oracle.sources_bos(centres, disc, z_obj, 10.0)
+    for key in ("x", "y", "z", "radiance", "diameter_index"):
+        assert np.array_equal(got[key], want[key]), key
+    assert np.array_equal(got["x"], call.src_x.astype(np.float32)) and np.array_equal(got["y"], call.src_y.astype(np.float32))
+    # --- Gaussian volume on the device == CPU restatement, bit for bit
+    for interp in (1, 2):
+        g = photon.volume_gaussian(40, sp, org, 1.225, 0.2, centre, 8.0e3 * 66300.0 / 66300.0, interp)
+        o = oracle.volume_gaussian(40, sp, org, 1.225, 0.2, centre, 8.0e3, interp)
+        assert_bit_equal(g.download(interp == 2), o.download(interp == 2), f"gaussian volume interp {interp}")
+        assert g.info().data_min == o.info().data_min and g.info().step_size == o.info().step_size
+        if interp == 2:
+            vol = g
+        else:
+            g.free()
+        o.free()
+    # --- render: scene from generated sources + generated volume == scene from host arrays + host density
+    vol_host = photon.volume_from_density(rho, sp, org, 2)
+    H, W = call.image_shape
+    imgs = []
+    for scene, v in ((photon.scene_create_from_sources(call, src), vol), (photon.scene_create(call), vol_host)):
+        img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+        st = scene.trace(img.data_ptr(), v, 2, want_stats=True)
+        assert st.rays_launched == call.num_rays and st.rk_iterations > 0
+        imgs.append(img.cpu().numpy())
+        scene.free()
+    assert imgs[0].any() and rel_l2(imgs[0], imgs[1]) <= IMAGE_TOL          # (volumes differ by the exp's last ulp)
+    src.free(); vol.free(); vol_host.free()
+    # --- PIV field: bit-identical to the CPU restatement, with and without a diameter distribution
+    lo, hi = (-3.0e4, -3.0e4, -7.5e3), (3.0e4, 3.0e4, 7.5e3)
+    cdf = np.cumsum(np.full(27, 1.0 / 27.0))
+    for c in (None, cdf):
+        s = photon.sources_piv(1234, 50_001, lo, hi, z_obj, 730.0, 500.0, c)
+        got, want = s.download(), oracle.sources_piv(1234, 50_001, lo, hi, z_obj, 730.0, 500.0, c)
+        for key in ("x", "y", "z", "radiance", "diameter_index"):
+            assert np.array_equal(got[key], want[key]), key
+        s.free()
+    # a PIV scene straight from the generator renders like the same sources passed through the host
+    pcall = scenes.piv_scene(n_particles=300, rays_per_source=200, mie=True, polydisperse=True, seed=3)
+    s = photon.sources_piv(77, 300, lo, hi, z_obj, 730.0, 500.0, cdf)
+    d = s.download()
+    pcall.src_x, pcall.src_y, pcall.src_z = d["x"], d["y"], d["z"]
+    pcall.src_radiance, pcall.src_diameter_index = d["radiance"], d["diameter_index"]
+    host_img = photon.render(pcall)
+    scene = photon.scene_create_from_sources(pcall, s)
+    img = torch.zeros(host_img.size, dtype=torch.float32, device="cuda")
+    scene.trace(img.data_ptr())
+    assert host_img.any() and np.array_equal(img.cpu().numpy().reshape(host_img.shape), host_img)
+    o_img, _ = oracle.render(pcall)
+    assert rel_l2(host_img, o_img) <= IMAGE_TOL
+    scene.free(); s.free()
+
+
 def _centroid(img):
     yy, xx = np.mgrid[0:img.shape[0], 0:img.shape[1]]
     w = img.astype(np.float64)
