@@ -64,16 +64,20 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
         for (int a = 0; a < 4; a++) t[r % D][a] = ldtexel(blk + r * 4 + a);
     }
     f4 acc = f4{0, 0, 0, 0}, plane = f4{0, 0, 0, 0};
+    float wx0 = wx[0];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         if (r + PHOTON_LDS_AHEAD < 16) {
 #pragma unroll
             for (int a = 0; a < 4; a++) t[(r + PHOTON_LDS_AHEAD) % D][a] = ldtexel(blk + (r + PHOTON_LDS_AHEAD) * 4 + a);
         }
-        asm volatile("" ::: "memory");
+        // the row's FMAs start from wx0: routing it through the barrier keeps them BELOW the reads just
+        // issued (ALU instructions are otherwise free to move above a memory barrier, which shrinks the
+        // read-ahead distance to a fraction of a row)
+        asm volatile("" : "+v"(wx0) : : "memory");
         const int b = r & 3, c = r >> 2;
         const f4 t0 = t[r % D][0], t1 = t[r % D][1], t2 = t[r % D][2], t3 = t[r % D][3];
-        f4 q = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
+        f4 q = f4{wx0 * t0.x, wx0 * t0.y, wx0 * t0.z, wx0 * t0.w};
         q = f4{fmaf(wx[1], t1.x, q.x), fmaf(wx[1], t1.y, q.y), fmaf(wx[1], t1.z, q.z), fmaf(wx[1], t1.w, q.w)};
         q = f4{fmaf(wx[2], t2.x, q.x), fmaf(wx[2], t2.y, q.y), fmaf(wx[2], t2.z, q.z), fmaf(wx[2], t2.w, q.w)};
         q = f4{fmaf(wx[3], t3.x, q.x), fmaf(wx[3], t3.y, q.y), fmaf(wx[3], t3.z, q.z), fmaf(wx[3], t3.w, q.w)};
