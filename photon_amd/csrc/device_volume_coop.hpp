@@ -152,8 +152,18 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     return acc;
 }
 
+// The trilinear blend with per-lane, clamped addressing (incoherent waves).  Not inlined, for the same
+// reason as cubic_gather_fn: it is the rare path and would otherwise sit, with its eight address
+// computations, at every sampler call site of the march.
+__device__ __attribute__((noinline)) f4 linear_gather_fn(const f4 *__restrict__ tex, int nx, int ny, int nz, float x,
+                                                         float y, float z) {
+    const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
+    const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
+    return linear_taps<true>(tex, nx, ny, nz, (int)fi, (int)fj, (int)fk, xb - fi, yb - fj, zb - fk);
+}
+
 __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
-                                                float x, float y, float z) {
+                                                float x, float y, float z, int &tile_key) {
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
     const float a = xb - fi, b = yb - fj, c = zb - fk;
@@ -169,14 +179,18 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         const int leader = __ffsll((long long)todo) - 1;
         const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
                   ck = __builtin_amdgcn_readlane(bk, leader);
-        const int tx = clampi(ci + ta, 0, v.nx - 1), ty = clampi(cj + tb, 0, v.ny - 1),
-                  tz = clampi(ck + tc, 0, v.nz - 1);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 8) {
-            const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-            *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
+        if (!PHOTON_TILE_REUSE || key != tile_key) {            // wave-uniform: the 2x2x2 block is not parked yet
+            const int tx = clampi(ci + ta, 0, v.nx - 1), ty = clampi(cj + tb, 0, v.ny - 1),
+                      tz = clampi(ck + tc, 0, v.nz - 1);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 8) {
+                const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+                *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            tile_key = key;
         }
-        __builtin_amdgcn_wave_barrier();
         if (!done && bi == ci && bj == cj && bk == ck) {
             // blk[tc*4 + tb*2 + ta]; same lerp tree as tex3d_linear
             const f4 c00 = lerp4(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4(ldtexel(blk + 2), ldtexel(blk + 3), a);
@@ -187,7 +201,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (!done) acc = linear_taps<true>(tex, v.nx, v.ny, v.nz, bi, bj, bk, a, b, c);
+    if (!done) acc = linear_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);
     return acc;
 }
 
@@ -233,9 +247,12 @@ __device__ __forceinline__ f3 lookup_index_u(f3 pos, const MarchU &u) {
 __device__ __forceinline__ bool can_access_u(const MarchU &u, f3 l) {
     return !(l.x < 0 || l.y < 0 || l.z < 0 || l.x >= u.fnx || l.y >= u.fny || l.z >= u.fnz);
 }
-__device__ __forceinline__ bool inside_box_u(f3 p, const MarchU &u, f3 l) {
-    if (p.x < u.minx || p.y < u.miny || p.z < u.minz || p.x >= u.maxx || p.y >= u.maxy || p.z >= u.maxz) return false;
-    return can_access_u(u, l);
+// The reference's second test (0 <= lookup < n, .h:236-248) cannot fail once the first has passed:
+// min <= p < max puts (p - min) * scale in [0, 1 + 2^-23], so lookup = 1 + that * (n - 2) lies in
+// [1, n - 1 + (n - 2) * 2^-23] -- inside [0, n) for every n the samplers accept; a NaN position passes
+// both tests alike.  (The CPU oracle evaluates both.)
+__device__ __forceinline__ bool inside_box_u(f3 p, const MarchU &u, f3) {
+    return !(p.x < u.minx || p.y < u.miny || p.z < u.minz || p.x >= u.maxx || p.y >= u.maxy || p.z >= u.maxz);
 }
 
 // Statistics.  MarchCount (device_volume.hpp) counts per lane -- photon_trace_volume_rays reports
@@ -252,7 +269,7 @@ __device__ __forceinline__ void count_iterations(WaveCount &mc, bool yes) { mc.i
 template <int INTERP, class CNT>
 __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need, f3 lookup,
                                           const f4 &val_prev, CNT &mc, int &tile_key) {
-    f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z)
+    f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, tile_key)
                          : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, tile_key);
     count_samples(mc, need);
     if (INTERP == 1) {
@@ -260,7 +277,7 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
         const bool low = need && val.w < v.data_min;
         const bool repair = low && val_prev.w == 0;
         if (__ballot(repair) != 0) {                            // wave-uniform, rare
-            const f4 t = tex3d_linear_coop(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1);
+            const f4 t = tex3d_linear_coop(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, tile_key);
             count_samples(mc, repair);
             if (repair) val = f4{t.x, t.y, t.z, ambient - 1};
         }

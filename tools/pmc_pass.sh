@@ -6,7 +6,7 @@ tag=$1; shift
 out=$PWD/gpurun_out/pmc_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d "$out" -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample-rays 0 > "$out/bench.log" 2>&1
+rocprofv3 --pmc "$@" --output-format csv -d "$out" -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample-rays 0 $PHOTON_BENCH_ARGS > "$out/bench.log" 2>&1
 cd "$GRAFT_REPO_ROOT"
 python3 - "$out" <<'PY'
 import csv, glob, collections, sys
