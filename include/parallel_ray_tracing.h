@@ -131,6 +131,7 @@ typedef struct camera_design_t {
  *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
  *                                reference seeds cuRAND with time(NULL); default 0x5eed)
  *   PHOTON_ELEMENT_TRAIN=reference|sequential   element-group walk (photon_scene_set_element_train)
+ *   PHOTON_RAY_ORDER=source|lens|auto           lane order of a launch (photon_scene_set_ray_order)
  *   PHOTON_DEVICES=all|0,1,..    shard the sources of one call over several GPUs (one host thread
  *                                and one private image per device, summed at the end); default:
  *                                the calling thread's current device
@@ -237,6 +238,16 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
  * chosen per ray by nearest centre on the element plane (design: perform_ray_tracing_03.py:1254-1485).
  * start_ray_tracing reads it from PHOTON_ELEMENT_TRAIN=reference|sequential. */
 int photon_scene_set_element_train(photon_scene_t *scene, int mode);
+
+/* Order in which a launch lays its rays over the GPU's lanes (results are a sum: the image does not depend
+ * on it beyond f64 summation order).  0 = source-major, the reference's thread order (.cu:1988-2006): best
+ * when a source's ray cone is narrower than a volume texel (BOS).  1 = lens-major over spatially sorted
+ * sources: a wave carries 64 neighbouring sources aimed at one lens point -- best when the cone is as wide as
+ * the aperture (PIV through a volume).  2 = choose per launch from the cone width at the volume and the
+ * texel size (default).  Launches that write ray dumps or use gradient noise are always source-major; with
+ * mode 1 or 2 the [src_begin, src_end) of photon_trace counts sources in the sorted order.
+ * start_ray_tracing reads PHOTON_RAY_ORDER=source|lens|auto. */
+int photon_scene_set_ray_order(photon_scene_t *scene, int mode);
 
 /* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.

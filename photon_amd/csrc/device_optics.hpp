@@ -56,7 +56,30 @@ struct SceneDev {
     const int *all_sys_index;
     camera_design_t cam;
     NoiseDev noise;
+    // launch-slot -> (source, lens sample) mapping.  0 = source-major, the reference's order (.cu:1988-2006):
+    // slot r is ray r % rays_per_source of source src_begin + r / rays_per_source -- a wave holds the narrow cone
+    // of one BOS source.  1 = lens-major: slot r is lens sample r / S of the (r % S)-th source of this launch,
+    // sources taken in the spatial order src_perm -- a wave holds 64 neighbouring particles aimed at the SAME
+    // point of the lens (every source uses the same lens-sample table, .cu:2006), which is what stays
+    // coherent when the cone is as wide as the aperture (PIV through a volume).
+    int ray_order;
+    const int *src_perm;                // spatial order of the sources (lens-major only); nullptr = identity
 };
+
+// slot of this launch -> source index and lens-sample index; n_src = sources in this launch
+__device__ __forceinline__ void slot_to_ray(const SceneDev &sc, long long src_begin, unsigned n_rays, unsigned r, int &source,
+                                            int &local_ray) {
+    const unsigned rps = (unsigned)sc.rays_per_source;
+    if (sc.ray_order == 0) {
+        source = (int)(src_begin + r / rps);
+        local_ray = (int)(r % rps);
+    } else {
+        const unsigned n_src = n_rays / rps;
+        local_ray = (int)(r / n_src);
+        const long long pos = src_begin + r % n_src;
+        source = sc.src_perm ? sc.src_perm[pos] : (int)pos;
+    }
+}
 
 struct Ray {                            // light_ray_data_t
     f3 pos, dir;

@@ -32,6 +32,9 @@ namespace photon {
 #ifndef PHOTON_COOP_GROUPS
 #define PHOTON_COOP_GROUPS 4
 #endif
+#ifndef PHOTON_COOP_MIN_SHARE
+#define PHOTON_COOP_MIN_SHARE 2     // after the first, a cooperative pass needs >= 1/2 of the still-unserved lanes
+#endif
 #ifndef PHOTON_TILE_REUSE
 #define PHOTON_TILE_REUSE 1
 #endif
@@ -123,6 +126,11 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         const int leader = __ffsll((long long)todo) - 1;
         const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
                   ck = __builtin_amdgcn_readlane(bk, leader);
+        // A cooperative pass costs the whole wave one 64-tap chain however few lanes share the leader's
+        // block, the per-lane gather below serves ALL remaining lanes for about two or three such passes:
+        // keep going cooperatively only while the leader's group is a worthwhile share of what is left.
+        const bool mine = !done && bi == ci && bj == cj && bk == ck;
+        if (g > 0 && PHOTON_COOP_MIN_SHARE * __popcll(__ballot(mine)) < __popcll(todo)) break;       // wave-uniform
         // one coalesced-ish load instruction for the whole block: 16 rows of 64 contiguous bytes.
         // Interior blocks (the common case; a scalar test) need no per-texel clamping.
         // block id: base texels lie in [-1, n) per axis, so (c+1) fits n+1 values per axis
@@ -142,7 +150,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
             __builtin_amdgcn_wave_barrier();
             tile_key = key;
         }
-        if (!done && bi == ci && bj == cj && bk == ck) {
+        if (mine) {
             acc = cubic_taps_lds(blk, wx, wy, wz);
             done = true;
         }
@@ -179,6 +187,8 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         const int leader = __ffsll((long long)todo) - 1;
         const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
                   ck = __builtin_amdgcn_readlane(bk, leader);
+        const bool mine = !done && bi == ci && bj == cj && bk == ck;
+        if (g > 0 && PHOTON_COOP_MIN_SHARE * __popcll(__ballot(mine)) < __popcll(todo)) break;       // see tex3d_cubic_coop
         const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
         if (!PHOTON_TILE_REUSE || key != tile_key) {            // wave-uniform: the 2x2x2 block is not parked yet
             const int tx = clampi(ci + ta, 0, v.nx - 1), ty = clampi(cj + tb, 0, v.ny - 1),
@@ -191,7 +201,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
             __builtin_amdgcn_wave_barrier();
             tile_key = key;
         }
-        if (!done && bi == ci && bj == cj && bk == ck) {
+        if (mine) {
             // blk[tc*4 + tb*2 + ta]; same lerp tree as tex3d_linear
             const f4 c00 = lerp4(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4(ldtexel(blk + 2), ldtexel(blk + 3), a);
             const f4 c01 = lerp4(ldtexel(blk + 4), ldtexel(blk + 5), a), c11 = lerp4(ldtexel(blk + 6), ldtexel(blk + 7), a);

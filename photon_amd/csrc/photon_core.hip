@@ -323,8 +323,9 @@ __global__ __launch_bounds__(256) void march_rays_extra_kernel(VolumeDev v, int 
 __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st) {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
-    const unsigned rps = (unsigned)sc.rays_per_source;
-    const Ray ray = generate_ray(sc, (int)(src_begin + r / rps), (int)(r % rps));
+    int source, local_ray;
+    slot_to_ray(sc, src_begin, n_rays, r, source, local_ray);
+    const Ray ray = generate_ray(sc, source, local_ray);
     f3 p = ray.pos, d = ray.dir;
     p.z = (float)(p.z - (sc.z_offset + 750e3));                         // .cu:2045
     p = matvec(sc.cam.inverse_rotation_matrix, p);                      // camera -> world
@@ -401,6 +402,8 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
     if (r < n_rays) {
         Ray ray;
         bool alive = true;
+        int source, local_ray;
+        slot_to_ray(sc, src_begin, n_rays, r, source, local_ray);
         if (FROM_STATE) {                                              // back to the camera frame (.cu:2100-2122)
             f3 p = mk3(st.px[r], st.py[r], st.pz[r]);
             f3 d = mk3(st.dx[r], st.dy[r], st.dz[r]);
@@ -413,11 +416,11 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
             ray.wavelength = sc.beam_wavelength;
             alive = !(isnan3(ray.dir) || isnan3(ray.pos));              // .cu:2125-2129
         } else {
-            const unsigned rps = (unsigned)sc.rays_per_source;
-            ray = generate_ray(sc, (int)(src_begin + r / rps), (int)(r % rps));
+            ray = generate_ray(sc, source, local_ray);
         }
         const bool dumping = dump.final_pos != nullptr && r < (unsigned)dump.num_save;
-        const unsigned long long ray_id = (unsigned long long)src_begin * (unsigned)sc.rays_per_source + r;
+        // the ray's identity for the noise generator: independent of the launch order
+        const unsigned long long ray_id = (unsigned long long)source * (unsigned)sc.rays_per_source + (unsigned)local_ray;
         f3 fin = nan3();
         bool have_fin = false;
         if (alive) {
@@ -487,6 +490,9 @@ struct photon_scene {
     unsigned long long *d_counters = nullptr;
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ray_order_mode = 2;             // 0 source-major, 1 lens-major, 2 auto (photon_scene_set_ray_order)
+    float lens_z = 0.f;                 // element 0's centre, for the auto rule
+    int *d_perm = nullptr;              // spatial (Morton) order of the sources, built on first lens-major launch
 };
 
 template <typename T>
@@ -819,6 +825,7 @@ void photon_scene_free(photon_scene_t *s) {
     if (s->ws.radiance) (void)hipFree(s->ws.radiance);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_acc) (void)hipFree(s->d_acc);
+    if (s->d_perm) (void)hipFree(s->d_perm);
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -1041,6 +1048,9 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
             }
         }
         d.train_mode = 0;
+        d.ray_order = 0;
+        d.src_perm = nullptr;
+        s->lens_z = (float)element_center[0][2];
         if ((rc = upload(s, edp, (size_t)num_elements, &d.all_elems))) return bail(rc);
         if ((rc = upload(s, centers.data(), centers.size(), &d.all_centers))) return bail(rc);
         if ((rc = upload(s, planes.data(), planes.size(), &d.all_planes))) return bail(rc);
@@ -1078,6 +1088,12 @@ int photon_scene_set_element_train(photon_scene_t *s, int mode) {
     return 0;
 }
 
+int photon_scene_set_ray_order(photon_scene_t *s, int mode) {
+    if (!s || mode < 0 || mode > 2) return 1;
+    s->ray_order_mode = mode;
+    return 0;
+}
+
 }  // extern "C"
 
 // rays per launch: bounded so that 32-bit ray ids suffice and the state stays a few GB
@@ -1111,6 +1127,64 @@ static int end_accumulate(photon_scene *s, float *d_image, hipStream_t stream) {
 }
 
 // One launch group over sources [src_begin, src_end): n rays = sources * rays_per_source.
+// Spatial order of the sources for lens-major launches: Morton code of (x, y) on a 2^16 grid over the
+// sources' bounding box.  Built once per scene, on the host (O(n log n) on 8 n bytes; the sort is not on
+// the per-image path), kept in HBM.
+static int ensure_source_order(photon_scene *s) {
+    if (s->d_perm) return 0;
+    const size_t n = (size_t)s->dev.num_sources;
+    std::vector<float> x(n), y(n);
+    if (n) {
+        PH_CHECK(hipMemcpy(x.data(), s->dev.sx, n * sizeof(float), hipMemcpyDeviceToHost));
+        PH_CHECK(hipMemcpy(y.data(), s->dev.sy, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    float x0 = FLT_MAX, x1 = -FLT_MAX, y0 = FLT_MAX, y1 = -FLT_MAX;
+    for (size_t i = 0; i < n; i++) {
+        if (x[i] < x0) x0 = x[i];
+        if (x[i] > x1) x1 = x[i];
+        if (y[i] < y0) y0 = y[i];
+        if (y[i] > y1) y1 = y[i];
+    }
+    const double fx = x1 > x0 ? 65535.0 / ((double)x1 - x0) : 0.0, fy = y1 > y0 ? 65535.0 / ((double)y1 - y0) : 0.0;
+    auto spread = [](uint32_t v) {                                      // 16 bits -> every other bit of 32
+        v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    std::vector<std::pair<uint32_t, int>> keyed(n);
+    for (size_t i = 0; i < n; i++) {
+        const double qx = ((double)x[i] - x0) * fx, qy = ((double)y[i] - y0) * fy;
+        const uint32_t ix = qx == qx ? (uint32_t)qx : 0u, iy = qy == qy ? (uint32_t)qy : 0u;     // NaN -> 0
+        keyed[i] = {spread(ix) | (spread(iy) << 1), (int)i};
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) { return a.first < b.first; });
+    std::vector<int> perm(n);
+    for (size_t i = 0; i < n; i++) perm[i] = keyed[i].second;
+    PH_CHECK(hipMalloc((void **)&s->d_perm, std::max<size_t>(n, 1) * sizeof(int)));
+    if (n) PH_CHECK(hipMemcpy(s->d_perm, perm.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Which order a launch uses.  Lens-major pays off when the ray cone of a source is wider than the volume's
+// texels where it crosses the volume (then the 64 rays of ONE source fan out over many texel blocks, while
+// 64 neighbouring sources aimed at one lens point stay together); source-major otherwise (BOS: the cone is a
+// micron wide) and whenever something indexes rays by the reference's launch order (ray dumps) or the march
+// needs per-ray ids (gradient noise).
+static bool use_lens_major(const photon_scene *s, const photon_volume *vol, const DumpDev &dump) {
+    if (!vol || dump.final_pos || dump.inter_pos || s->dev.noise.add_ngrad || s->dev.rays_per_source < 2) return false;
+    if (s->ray_order_mode != 2) return s->ray_order_mode == 1;
+    const double z_obj = (double)s->dev.object_distance + s->dev.z_offset;             // camera frame
+    const double z_face = (double)vol->dev.min_bound.z + s->dev.z_offset + 750e3;      // the volume's lens-side face
+    const double span = z_obj - s->lens_z;
+    if (!(span > 0)) return false;
+    double frac = (z_obj - z_face) / span;
+    frac = frac < 0 ? 0 : (frac > 1 ? 1 : frac);
+    const double cone = (double)s->dev.ratio * s->dev.lens_pitch * frac;               // cone diameter at that face
+    const photon_volume_info_t &i = vol->info;
+    const double texel = std::min((double)i.grid_spacing[0], std::min((double)i.grid_spacing[1], (double)i.grid_spacing[2]));
+    return cone > texel;
+}
+
 static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
                         long long src_end, DumpDev dump, hipStream_t stream, bool timed) {
     double *d_image = s->d_acc;
@@ -1119,6 +1193,14 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     if (n64 > kMaxRaysPerLaunch) return 1;
     const unsigned n = (unsigned)n64;
     const dim3 block(256), grid((n + 255) / 256);
+    s->dev.ray_order = 0;
+    s->dev.src_perm = nullptr;
+    if (use_lens_major(s, vol, dump)) {
+        const int rc = ensure_source_order(s);
+        if (rc) return rc;
+        s->dev.ray_order = 1;
+        s->dev.src_perm = s->d_perm;
+    }
     if (vol) {
         int rc = ensure_workspace(s, n);
         if (rc) return rc;
@@ -1226,6 +1308,14 @@ int interpolation_from_env() {
 int element_train_from_env() {
     const char *e = getenv("PHOTON_ELEMENT_TRAIN");
     return e && (strcmp(e, "sequential") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
+}
+
+// PHOTON_RAY_ORDER=source|lens|auto (photon_scene_set_ray_order)
+int ray_order_from_env() {
+    const char *e = getenv("PHOTON_RAY_ORDER");
+    if (e && strcmp(e, "source") == 0) return 0;
+    if (e && strcmp(e, "lens") == 0) return 1;
+    return 2;
 }
 
 int cached_volume(const char *path, int interpolation, photon_volume **out) {
@@ -1344,6 +1434,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                         photon_scene_set_noise(sc, add_pos_noise, pos_noise_std, simulate_density_gradients && add_ngrad_noise,
                                                ngrad_noise_std, seed);
                         photon_scene_set_element_train(sc, element_train_from_env());
+                        photon_scene_set_ray_order(sc, ray_order_from_env());
                         photon_volume *v = nullptr;
                         float *d_img = nullptr;
                         int rc = 0;
@@ -1413,6 +1504,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
         photon_scene_set_noise(scene, add_pos_noise, pos_noise_std, simulate_density_gradients && add_ngrad_noise,
                                ngrad_noise_std, seed);
         photon_scene_set_element_train(scene, element_train_from_env());
+        photon_scene_set_ray_order(scene, ray_order_from_env());
     }
     photon_volume *vol = nullptr;
     if (simulate_density_gradients) {

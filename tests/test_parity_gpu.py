@@ -440,6 +440,47 @@ def test_scene_generation_on_device(photon, oracle, monkeypatch):
     scene.free(); s.free()
 
 
+def test_ray_order_does_not_change_the_image(photon, oracle, small_volume_file, monkeypatch):
+    """photon_scene_set_ray_order / PHOTON_RAY_ORDER: source-major (the reference's thread order), lens-major over
+    Morton-sorted sources (what keeps waves coherent for full-aperture cones through a volume) and the automatic
+    choice must render the same image -- also with position noise, whose generator is keyed by the ray's identity,
+    not by its launch slot -- and sharding the sorted order must still cover every source exactly once."""
+    import torch
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    monkeypatch.setenv("PHOTON_NOISE_SEED", "11")
+    oracle.set_noise_seed(11)
+    call = scenes.piv_scene(n_particles=700, rays_per_source=40, mie=True, polydisperse=True,
+                            density_grad_filename=small_volume_file, field_half_width=3.0e4, seed=5)
+    call.add_pos_noise, call.pos_noise_std = True, 0.3
+    o, st = oracle.render(call, interpolation=2)
+    assert st.rk_iterations > 0 and o.any()
+    images = {}
+    for order in ("source", "lens", "auto"):
+        monkeypatch.setenv("PHOTON_RAY_ORDER", order)
+        images[order] = photon.render(call)
+        assert rel_l2(images[order], o) <= IMAGE_TOL, (order, rel_l2(images[order], o))
+    assert rel_l2(images["lens"], images["source"]) <= IMAGE_TOL
+    oracle.set_noise_seed(0)
+    # device-resident API: lens-major shards [0, n/3) + [n/3, n) of the sorted order == one pass
+    call.add_pos_noise = False
+    vol = photon.volume_load_nrrd(small_volume_file, 2)
+    scene = photon.scene_create(call)
+    scene.set_ray_order(1)
+    H, W = call.image_shape
+    whole = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    parts = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    scene.trace(whole.data_ptr(), vol, 2)
+    cut = call.num_sources // 3
+    scene.trace(parts.data_ptr(), vol, 2, 0, cut)
+    scene.trace(parts.data_ptr(), vol, 2, cut, call.num_sources)
+    assert rel_l2(parts.cpu().numpy(), whole.cpu().numpy()) <= IMAGE_TOL
+    scene.set_ray_order(0)
+    ref = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    scene.trace(ref.data_ptr(), vol, 2)
+    assert rel_l2(whole.cpu().numpy(), ref.cpu().numpy()) <= IMAGE_TOL
+    scene.free(); vol.free()
+
+
 def _centroid(img):
     yy, xx = np.mgrid[0:img.shape[0], 0:img.shape[1]]
     w = img.astype(np.float64)
