@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--volume", type=int, default=256, help="grid points per axis of the density volume")
     ap.add_argument("--dots", type=int, default=200, help="BOS dots per GPU (x100 sources x500 rays)")
     ap.add_argument("--rays-per-source", type=int, default=500)
-    ap.add_argument("--cpu-sample-rays", type=int, default=50000, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-rays", type=int, default=500000, help="rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also verify a slice of the image against the oracle")
     return ap.parse_args()
 
