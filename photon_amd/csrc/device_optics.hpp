@@ -325,8 +325,10 @@ __device__ __noinline__ Ray element_train(const SceneDev &sc, Ray ray) {
 // propagate_rays_through_optical_system (.cu:1274-1381): sequential groups; a group with exactly
 // one member is propagated through element 0 (.cu:1331-1333); larger groups reach the
 // reference's empty multi-element stub and leave the ray unchanged.
+template <bool TRAIN>
 __device__ __forceinline__ Ray optical_system(const SceneDev &sc, Ray ray) {
-    if (sc.train_mode != 0) return element_train(sc, ray);
+    if (TRAIN) return element_train(sc, ray);           // separate kernel instantiation: keeps the call (and its
+                                                        // scratch frame) out of the default sensor kernel
     int seq = 0;
     const int n = sc.num_elements < kMaxElements ? sc.num_elements : kMaxElements;
     for (int k = 0; k < n; k++)

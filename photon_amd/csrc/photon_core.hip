@@ -390,8 +390,11 @@ __global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigne
 
 // Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241).  FROM_STATE=false
 // (no density gradients) generates the ray in place, so that path is one fused kernel.
-template <bool FROM_STATE>
-__global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
+#ifndef PHOTON_SENSOR_WAVES
+#define PHOTON_SENSOR_WAVES 2
+#endif
+template <bool FROM_STATE, bool TRAIN>
+__global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
                                                      double *image, DumpDev dump, unsigned long long *counters) {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     int taps = 0;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256) void sensor_kernel(SceneDev sc, long long src_
                 have_fin = true;
                 on_sensor = !isnan(fin.x);
             } else {
-                ray = optical_system(sc, ray);
+                ray = optical_system<TRAIN>(sc, ray);
                 if (!(isnan3(ray.dir) || isnan3(ray.pos))) {            // .cu:2172-2176
                     if (sc.cam.implement_diffraction) {
                         fin = sensor_diffraction(ray, sc.cam, req, sc.noise, ray_id);
@@ -1224,9 +1227,11 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
 #undef PH_MARCH
         PH_CHECK(hipGetLastError());
         if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
-        hipLaunchKernelGGL((sensor_kernel<true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<true, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        else hipLaunchKernelGGL((sensor_kernel<true, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     } else {
-        hipLaunchKernelGGL((sensor_kernel<false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<false, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        else hipLaunchKernelGGL((sensor_kernel<false, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     }
     PH_CHECK(hipGetLastError());
     return 0;
