@@ -440,6 +440,37 @@ def test_scene_generation_on_device(photon, oracle, monkeypatch):
     scene.free(); s.free()
 
 
+@pytest.mark.parametrize("interp", [1, 2])
+def test_odd_geometry(photon, oracle, workdir, interp, monkeypatch):
+    """The less-trodden corners in one scene: rotated camera (rotation / inverse rotation matrices, .cu:2045-2122),
+    non-square sensor, Cauchy dispersion (finite Abbe number, .cu:622-636) with lossy glass (absorbance +
+    transmission, .cu:838-853), and a volume with three different sizes and spacings that only part of the rays
+    cross."""
+    nz, ny, nx = 56, 48, 40
+    sp = (310.0, 270.0, 235.0)
+    org = (-0.5 * sp[0] * (nx - 1) + 1500.0, -0.5 * sp[1] * (ny - 1), 300000.0)
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    rho = (1.225 + 0.15 * np.exp(-(((x - 17.0) * sp[0]) ** 2 + ((y - 26.0) * sp[1]) ** 2 + ((z - 30.0) * sp[2]) ** 2)
+                                 / (2 * 2.5e3 ** 2))).astype(np.float32)
+    path = scenes.write_nrrd(os.path.join(workdir, "odd.nrrd"), rho, sp, org)
+    call = scenes.bos_scene(n_dots=40, points_per_dot=12, rays_per_source=64, density_grad_filename=path,
+                            field_half_width=1.2e4, seed=21)
+    ax, ay = np.deg2rad(0.4), np.deg2rad(-0.3)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    R = Rx @ Ry
+    call.camera.update(x_pixel_number=640, y_pixel_number=512, pixel_pitch=21.0, x_camera_angle=float(ax),
+                       y_camera_angle=float(ay), rotation_matrix=R, inverse_rotation_matrix=R.T)
+    props = call.elements[0]["element_properties"]
+    props.update(abbe_number=50.0, transmission_ratio=0.9, absorbance_rate=2.0e-6)
+    call.beam_wavelength = 532.0                                  # nm: the Cauchy formula's lambda_D/F/C are (.cu:622)
+    assert call.image_shape == (512, 640)
+    g, o, st = _render_both(photon, oracle, call, interp, monkeypatch)
+    assert 0 < st.rk_iterations < 52 * call.num_rays              # the rotated view clips the volume for part of the rays
+    assert st.rays_on_sensor > 0 and o.any()
+    assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+
+
 def test_ray_order_does_not_change_the_image(photon, oracle, small_volume_file, monkeypatch):
     """photon_scene_set_ray_order / PHOTON_RAY_ORDER: source-major (the reference's thread order), lens-major over
     Morton-sorted sources (what keeps waves coherent for full-aperture cones through a volume) and the automatic
