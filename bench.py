@@ -225,7 +225,7 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if args.cpu_sample_rays > 0:
+        if args.cpu_sample_rays > 0 and world == 1:      # the CPU baseline is reported at N=1 only
             cpu = cpu_baseline(lambda n_sources: make_call(seed=1, n_sources=n_sources), vol_path, interp,
                                args.cpu_sample_rays, args.rays_per_source)
         out = {
