@@ -30,7 +30,7 @@ HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp"
 # -munsafe-fp-atomics: atomicAdd(float*) is one global_atomic_add_f32, never a CAS loop.
 # f32 divide / sqrt stay correctly rounded (hipcc default; made explicit).
 # -fno-slp-vectorize: v_pk_*_f32 issue at half the rate of the unpacked forms on gfx950 (measured:
-#   build/ubench/fma_rate.hip), so SLP packing only adds operand shuffles.
+#   tools/ubench/fma_rate.hip), so SLP packing only adds operand shuffles.
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
     "-munsafe-fp-atomics", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize",

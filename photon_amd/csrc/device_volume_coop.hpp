@@ -45,7 +45,7 @@ constexpr int kCoopGroups = PHOTON_COOP_GROUPS;      // distinct texel blocks se
 
 // 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
 // is one broadcast ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues
-// in 4 cycles against 2 for v_fma_f32 (measured, build/ubench/fma_rate.hip), so packing buys no
+// in 4 cycles against 2 for v_fma_f32 (measured, tools/ubench/fma_rate.hip), so packing buys no
 // throughput and costs the (w,w) operand splats; the library is built with -fno-slp-vectorize.
 //
 // Written as a rolling pipeline over the 16 texel rows: the reads of row r+PHOTON_LDS_AHEAD are issued
