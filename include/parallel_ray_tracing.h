@@ -127,6 +127,8 @@ typedef struct camera_design_t {
  * Environment knobs (the ABI has no room for new arguments):
  *   PHOTON_INTERP=linear|cubic   volume sampler (default linear = the reference's
  *                                hard-coded interpolation_scheme 1, .cu:3330)
+ *   PHOTON_TEX_WEIGHTS=exact|fixed8   trilinear weights: exact f32 (default) or 8 fractional bits like
+ *                                the texture unit the reference runs on (photon_volume_set_weight_bits)
  *   PHOTON_VERBOSE=1             progress / timing on stdout
  *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
  *                                reference seeds cuRAND with time(NULL); default 0x5eed)
@@ -200,6 +202,12 @@ int photon_volume_from_density(const float *rho, int nx, int ny, int nz,
                                const double spacing[3], const double origin[3],
                                int interpolation, photon_volume_t **out);
 int photon_volume_info(const photon_volume_t *vol, photon_volume_info_t *info);
+/* Trilinear interpolation weights: bits = 0 (default) exact f32; bits = 8 rounds them to 8 fractional bits, the
+ * 9-bit fixed-point weights CUDA's linear texture filter uses (CUDA C Programming Guide, "Linear Filtering") --
+ * i.e. what the reference's tex3D() fetches (trace_rays_through_density_gradients.h:1052 ...) compute with on
+ * NVIDIA hardware.  Takes effect for every later sample / trace of this volume; the tricubic sampler (always
+ * the exact 64-tap sum) is unaffected.  start_ray_tracing reads PHOTON_TEX_WEIGHTS=exact|fixed8. */
+int photon_volume_set_weight_bits(photon_volume_t *vol, int bits);
 /* Copy the float4 texels (grad x,y,z, n-1) -- or the B-spline coefficients when
  * interpolation==2 and coefficients!=0 -- back to the host: f32[nz*ny*nx*4]. */
 int photon_volume_download(const photon_volume_t *vol, int coefficients, float *out);

@@ -733,6 +733,7 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
     d.step_size = step;
     d.data_min = data_min;
     d.interpolation = interpolation;
+    d.weight_scale = 0.f;
     d.texels = v->d_texels;
     d.coeffs = v->d_coeffs;
     photon_volume_info_t &info = v->info;
@@ -758,6 +759,12 @@ int photon_volume_load_nrrd(const char *path, int interpolation, photon_volume_t
         printf("photon: NRRD %s  sizes %d %d %d  spacings %g %g %g  origin (%g,%g,%g)\n", path, dims[0], dims[1], dims[2],
                spacing[0], spacing[1], spacing[2], origin[0], origin[1], origin[2]);
     return photon_volume_from_density(rho.data(), dims[0], dims[1], dims[2], spacing, origin, interpolation, out);
+}
+
+int photon_volume_set_weight_bits(photon_volume_t *vol, int bits) {
+    if (!vol || bits < 0 || bits > 23) return 1;
+    vol->dev.weight_scale = bits ? (float)(1 << bits) : 0.f;
+    return 0;
 }
 
 int photon_volume_info(const photon_volume_t *vol, photon_volume_info_t *info) {
@@ -1323,6 +1330,13 @@ int ray_order_from_env() {
     return 2;
 }
 
+// PHOTON_TEX_WEIGHTS=exact|fixed8: trilinear weights as exact f32 (default) or as the reference's texture unit
+// holds them (8 fractional bits)
+int weight_bits_from_env() {
+    const char *e = getenv("PHOTON_TEX_WEIGHTS");
+    return e && (strcmp(e, "fixed8") == 0 || strcmp(e, "8") == 0) ? 8 : 0;
+}
+
 int cached_volume(const char *path, int interpolation, photon_volume **out) {
     struct stat st;
     if (stat(path, &st) != 0) {
@@ -1444,6 +1458,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                         float *d_img = nullptr;
                         int rc = 0;
                         if (simulate_density_gradients) rc = cached_volume(density_grad_filename, interpolation_from_env(), &v);
+                        if (!rc && v) photon_volume_set_weight_bits(v, weight_bits_from_env());
                         if (!rc && hipMalloc((void **)&d_img, npix * sizeof(float)) != hipSuccess) rc = 3;
                         if (!rc && hipMemset(d_img, 0, npix * sizeof(float)) != hipSuccess) rc = 3;
                         if (!rc) rc = photon_trace(sc, v, ray_tracing_algorithm, b, e2, d_img, nullptr, nullptr);
@@ -1514,6 +1529,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
     photon_volume *vol = nullptr;
     if (simulate_density_gradients) {
         if (cached_volume(density_grad_filename, interpolation_from_env(), &vol)) { cleanup(); return; }
+        photon_volume_set_weight_bits(vol, weight_bits_from_env());
     }
     const int W = camera_design_p->x_pixel_number, H = camera_design_p->y_pixel_number;
     const size_t npix = (size_t)W * H;

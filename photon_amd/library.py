@@ -19,7 +19,7 @@ from .ray_tracing import (RayTracingCall, bind_start_ray_tracing, camera_design_
 # every symbol include/parallel_ray_tracing.h declares
 DECLARED_SYMBOLS = (
     "start_ray_tracing", "photon_set_device", "photon_rand_table", "photon_volume_load_nrrd",
-    "photon_volume_from_density", "photon_volume_info", "photon_volume_download", "photon_volume_sample",
+    "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
     "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_trace",
     "photon_trace_volume_rays", "photon_version",
     # section 3: scene generation on the device
@@ -73,6 +73,7 @@ class PhotonLibrary:
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                  ctypes.POINTER(ctypes.c_void_p)]
         L.photon_volume_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(photon_volume_info_t)]
+        L.photon_volume_set_weight_bits.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.photon_volume_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.photon_volume_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.photon_volume_free.argtypes = [ctypes.c_void_p]
@@ -224,6 +225,10 @@ class Volume:
         i = photon_volume_info_t()
         self._lib._check(self._lib.lib.photon_volume_info(self.handle, ctypes.byref(i)), "photon_volume_info")
         return i
+
+    def set_weight_bits(self, bits: int):
+        """Trilinear weights: 0 = exact f32, 8 = the texture unit's 8 fractional bits."""
+        self._lib._check(self._lib.lib.photon_volume_set_weight_bits(self.handle, int(bits)), "photon_volume_set_weight_bits")
 
     def download(self, coefficients: bool = False) -> np.ndarray:
         i = self.info()

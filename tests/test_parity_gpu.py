@@ -471,6 +471,43 @@ def test_odd_geometry(photon, oracle, workdir, interp, monkeypatch):
     assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
 
 
+def test_texture_unit_weights(photon, oracle, small_volume_file, monkeypatch):
+    """PHOTON_TEX_WEIGHTS=fixed8 / photon_volume_set_weight_bits(8): trilinear weights rounded to 8 fractional
+    bits, the documented arithmetic of the texture unit the reference's tex3D() runs on.  Sampler and marched
+    rays bit-exact against the CPU restatement, rendered image to the parity bar."""
+    rho, sp, org = scenes.bos_volume(48)
+    g, o = photon.volume_from_density(rho, sp, org, 1), oracle.volume_from_density(rho, sp, org, 1, tex_frac_bits=8)
+    g.set_weight_bits(8)
+    i = g.info()
+    rng = np.random.default_rng(23)
+    coords = np.stack([rng.uniform(-1, i.nx + 1, 20000), rng.uniform(-1, i.ny + 1, 20000), rng.uniform(-1, i.nz + 1, 20000)], 1)
+    assert_bit_equal(g.sample(coords), o.sample(coords), "8-bit-weight sampler")
+    lo, hi = np.array(i.min_bound), np.array(i.max_bound)
+    pos = np.stack([rng.uniform(lo[a], hi[a], 3000) for a in range(3)], 1)
+    pos[:, 2] = hi[2] + 2000.0
+    d = np.stack([rng.normal(0, 0.05, 3000), rng.normal(0, 0.05, 3000), -np.ones(3000)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for algorithm in (1, 2):
+        gp, gd, gs = g.trace_rays(pos, d, algorithm)
+        op, od, os_ = o.trace_rays(pos, d, algorithm)
+        assert np.array_equal(gs, os_)
+        assert_bit_equal(gp, op, "positions, 8-bit weights")
+        assert_bit_equal(gd, od, "directions, 8-bit weights")
+    g.set_weight_bits(0)
+    exact_p, _, _ = g.trace_rays(pos, d, 2)
+    assert not np.array_equal(exact_p, gp)
+    g.free(); o.free()
+    # through the ABI
+    call = scenes.bos_scene(n_dots=8, points_per_dot=20, rays_per_source=100, density_grad_filename=small_volume_file)
+    monkeypatch.setenv("PHOTON_INTERP", "linear")
+    exact = photon.render(call)
+    monkeypatch.setenv("PHOTON_TEX_WEIGHTS", "fixed8")
+    fixed = photon.render(call)
+    ref, _ = oracle.render(call, interpolation=1, tex_frac_bits=8)
+    assert rel_l2(fixed, ref) <= IMAGE_TOL, rel_l2(fixed, ref)
+    assert not np.array_equal(fixed, exact)                     # (a smooth field: the two differ by ~1e-5 rel. L2)
+
+
 def test_ray_order_does_not_change_the_image(photon, oracle, small_volume_file, monkeypatch):
     """photon_scene_set_ray_order / PHOTON_RAY_ORDER: source-major (the reference's thread order), lens-major over
     Morton-sorted sources (what keeps waves coherent for full-aperture cones through a volume) and the automatic
