@@ -11,14 +11,15 @@
 //   * the march is WAVE-SYNCHRONOUS: all 64 lanes stay in the loop until the last ray of the wave
 //     has left the volume (finished lanes are predicated off), so every lane is available for
 //     cooperative work at each sample;
-//   * lanes are grouped by base texel (a short waterfall over the distinct blocks of the wave);
-//     for each group the whole wave fetches the block with ONE load instruction -- lane l loads
-//     texel (l&3, (l>>2)&3, l>>4) of the block, clamp-to-edge applied per texel, 64 lanes x 16 B --
-//     and parks it in the wave's 1 KiB LDS tile;
-//   * the lanes of the group then run the separable 64-tap fmaf chain reading the texels back
-//     with broadcast ds_read_b128 (all lanes read the same address: conflict-free).
-//   * waves that are not coherent (more than kCoopGroups distinct blocks) finish the remaining
-//     lanes with the per-lane gather.
+//   * COHERENT waves (every sampling lane wants the same 4x4x4 / 2x2x2 block: BOS, always, except where a
+//     wave straddles two sources or a texel boundary): the whole wave fetches the block with ONE load
+//     instruction -- lane l loads texel (l&3, (l>>2)&3, l>>4), clamp-to-edge per texel, 64 lanes x 16 B --
+//     parks it in the wave's 1 KiB LDS tile, and the lanes run the separable 64-tap fmaf chain reading
+//     the texels back with broadcast ds_read_b128 (all lanes read the same address: conflict-free);
+//   * INCOHERENT waves (full-aperture cones): the wave parks an 8x8x4 (8x8x2) BRICK of texels around the
+//     first unserved lane's block -- four (two) loads per lane -- and every lane whose block lies within
+//     two (three) texels of it runs its chain from the brick in one pass, reading its own addresses; up to
+//     PHOTON_BRICK_PASSES bricks per sample, then the per-lane gather for the stragglers.
 //
 // Every path evaluates the same fmaf chain in the same order: results are bit-identical to the
 // per-lane samplers in device_volume.hpp and to the CPU oracle.
@@ -29,19 +30,12 @@
 namespace photon {
 
 
-#ifndef PHOTON_COOP_GROUPS
-#define PHOTON_COOP_GROUPS 4
-#endif
-#ifndef PHOTON_COOP_MIN_SHARE
-#define PHOTON_COOP_MIN_SHARE 2     // after the first, a cooperative pass needs >= 1/2 of the still-unserved lanes
+#ifndef PHOTON_BRICK_PASSES
+#define PHOTON_BRICK_PASSES 6       // bricks parked per sample before the remaining lanes fall back to the per-lane gather
 #endif
 #ifndef PHOTON_TILE_REUSE
 #define PHOTON_TILE_REUSE 1
 #endif
-#ifndef PHOTON_INTERIOR_FAST
-#define PHOTON_INTERIOR_FAST 0      // measured: the scalar interior test + second code path costs 2.5 % (88.0 vs 90.1 ms)
-#endif
-constexpr int kCoopGroups = PHOTON_COOP_GROUPS;      // distinct texel blocks served cooperatively per sample
 
 // 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
 // is one broadcast ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues
@@ -57,14 +51,17 @@ constexpr int kCoopGroups = PHOTON_COOP_GROUPS;      // distinct texel blocks se
 #ifndef PHOTON_LDS_AHEAD
 #define PHOTON_LDS_AHEAD 1          // rows read ahead (16 VGPRs each); 1, 2, 3 measure the same, 1 is the leanest
 #endif
+// RS / SS: texels between consecutive rows / z-slabs of the parked data (4 / 16 for the 4x4x4 tile, 8 / 64
+// for the 8x8x4 brick of incoherent waves).
+template <int RS, int SS>
 __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4], const float (&wy)[4],
-                                                  const float (&wz)[4]) {
+                                             const float (&wz)[4]) {
     constexpr int D = PHOTON_LDS_AHEAD + 1;                     // ring of rows in registers
     f4 t[D][4];
 #pragma unroll
     for (int r = 0; r < PHOTON_LDS_AHEAD; r++) {
 #pragma unroll
-        for (int a = 0; a < 4; a++) t[r % D][a] = ldtexel(blk + r * 4 + a);
+        for (int a = 0; a < 4; a++) t[r % D][a] = ldtexel(blk + (r >> 2) * SS + (r & 3) * RS + a);
     }
     f4 acc = f4{0, 0, 0, 0}, plane = f4{0, 0, 0, 0};
     float wx0 = wx[0];
@@ -72,7 +69,8 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     for (int r = 0; r < 16; r++) {
         if (r + PHOTON_LDS_AHEAD < 16) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) t[(r + PHOTON_LDS_AHEAD) % D][a] = ldtexel(blk + (r + PHOTON_LDS_AHEAD) * 4 + a);
+            for (int a = 0; a < 4; a++)
+                t[(r + PHOTON_LDS_AHEAD) % D][a] = ldtexel(blk + ((r + PHOTON_LDS_AHEAD) >> 2) * SS + ((r + PHOTON_LDS_AHEAD) & 3) * RS + a);
         }
         // the row's FMAs start from wx0: routing it through the barrier keeps them BELOW the reads just
         // issued (ALU instructions are otherwise free to move above a memory barrier, which shrinks the
@@ -106,6 +104,7 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 // its block already there and skips the fetch.
 __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
                                                float x, float y, float z, int &tile_key) {
+    f4 *const brick = blk + 64;                                 // the wave's 8x8x4 brick follows its 4x4x4 tile
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
     const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
     float wx[4], wy[4], wz[4];
@@ -114,49 +113,66 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
     const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
     const int lane = threadIdx.x & 63;
-    const int ta = lane & 3, tb = (lane >> 2) & 3, tc = lane >> 4;
-    // this lane's texel of an INTERIOR block, relative to the block's corner texel (no clamping)
-    const int lane_off = ((tc - 1) * v.ny + (tb - 1)) * v.nx + (ta - 1);
     f4 acc = f4{0, 0, 0, 0};
     bool done = !need;
-#pragma unroll 1
-    for (int g = 0; g < kCoopGroups; g++) {
-        const unsigned long long todo = __ballot(!done);
-        if (todo == 0) break;                                   // wave-uniform
+    unsigned long long todo = __ballot(!done);
+    if (todo == 0) return acc;                                  // wave-uniform
+    {
+        // COHERENT wave -- every sampling lane wants the block of the first one (BOS: always, except where a
+        // wave straddles two sources or a cone straddles a texel boundary): one load instruction for the
+        // whole 4x4x4 block, lane l <-> texel (l&3, (l>>2)&3, l>>4), clamp-to-edge per texel, parked in the
+        // tile; then the chain with broadcast reads.
         const int leader = __ffsll((long long)todo) - 1;
         const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
                   ck = __builtin_amdgcn_readlane(bk, leader);
-        // A cooperative pass costs the whole wave one 64-tap chain however few lanes share the leader's
-        // block, the per-lane gather below serves ALL remaining lanes for about two or three such passes:
-        // keep going cooperatively only while the leader's group is a worthwhile share of what is left.
         const bool mine = !done && bi == ci && bj == cj && bk == ck;
-        if (g > 0 && PHOTON_COOP_MIN_SHARE * __popcll(__ballot(mine)) < __popcll(todo)) break;       // wave-uniform
-        // one coalesced-ish load instruction for the whole block: 16 rows of 64 contiguous bytes.
-        // Interior blocks (the common case; a scalar test) need no per-texel clamping.
-        // block id: base texels lie in [-1, n) per axis, so (c+1) fits n+1 values per axis
-        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-        if (!PHOTON_TILE_REUSE || key != tile_key) {            // wave-uniform (SALU compare)
-            unsigned idx;
-            if (PHOTON_INTERIOR_FAST && ci >= 1 && ci + 2 < v.nx && cj >= 1 && cj + 2 < v.ny && ck >= 1 && ck + 2 < v.nz) {
-                idx = (unsigned)((ck * v.ny + cj) * v.nx + ci + lane_off);
-            } else {
-                const int tx = clampi(ci - 1 + ta, 0, v.nx - 1), ty = clampi(cj - 1 + tb, 0, v.ny - 1),
-                          tz = clampi(ck - 1 + tc, 0, v.nz - 1);
-                idx = (unsigned)((tz * v.ny + ty) * v.nx + tx);
+        if (__ballot(mine) == todo) {                           // wave-uniform
+            // block id: base texels lie in [-1, n) per axis, so (c+1) fits n+1 values per axis
+            const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
+            if (!PHOTON_TILE_REUSE || key != tile_key) {        // wave-uniform (SALU compare)
+                const int tx = clampi(ci - 1 + (lane & 3), 0, v.nx - 1), ty = clampi(cj - 1 + ((lane >> 2) & 3), 0, v.ny - 1),
+                          tz = clampi(ck - 1 + (lane >> 4), 0, v.nz - 1);
+                const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));      // < 2^31 texels (checked on the host)
+                __builtin_amdgcn_wave_barrier();
+                *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+                __builtin_amdgcn_wave_barrier();
+                tile_key = key;
             }
-            const f4 t = ldtexel(tex + idx);                    // < 2^31 texels (checked on the host)
+            if (mine) acc = cubic_taps_lds<4, 16>(blk, wx, wy, wz);
             __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
-            __builtin_amdgcn_wave_barrier();
-            tile_key = key;
+            return acc;
         }
-        if (mine) {
-            acc = cubic_taps_lds(blk, wx, wy, wz);
+    }
+    // INCOHERENT wave (full-aperture cones, source boundaries: the lanes' blocks form a patch a few texels wide
+    // in one z-slab).  Serving it group by group would cost the whole wave one chain per distinct block.
+    // Instead: park the 8x8x4 BRICK around the first unserved lane's block -- four loads per lane -- and let
+    // every lane whose block lies within +-2 texels of it in x and y (same z) run its chain from there in ONE
+    // pass, each lane reading its own addresses.  Same chain, same order, same bits.
+#pragma unroll 1
+    for (int pass = 0; pass < PHOTON_BRICK_PASSES && todo != 0; pass++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
+                  ck = __builtin_amdgcn_readlane(bk, leader);
+        const int di = bi - ci + 2, dj = bj - cj + 2;
+        const bool in_brick = !done && bk == ck && (unsigned)di <= 4u && (unsigned)dj <= 4u;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = lane + 64 * j;
+            const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
+                      tz = clampi(ck - 1 + (t >> 6), 0, v.nz - 1);
+            const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+            *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (in_brick) {
+            acc = cubic_taps_lds<8, 64>(brick + (dj * 8 + di), wx, wy, wz);
             done = true;
         }
         __builtin_amdgcn_wave_barrier();
+        todo = __ballot(!done);
     }
-    if (!done) acc = cubic_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);                       // incoherent wave
+    if (!done) acc = cubic_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);                       // stragglers
     return acc;
 }
 
@@ -173,6 +189,7 @@ __device__ __attribute__((noinline)) f4 linear_gather_fn(const f4 *__restrict__ 
 
 __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
                                                 float x, float y, float z, int &tile_key) {
+    f4 *const brick = blk + 64;                                 // 8x8x2 texels around the leader for incoherent waves
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
     float a = xb - fi, b = yb - fj, c = zb - fk;
@@ -181,39 +198,69 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     }
     const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
     const int lane = threadIdx.x & 63;
-    const int ta = lane & 1, tb = (lane >> 1) & 1, tc = (lane >> 2) & 1;
     f4 acc = f4{0, 0, 0, 0};
     bool done = !need;
-#pragma unroll 1
-    for (int g = 0; g < kCoopGroups; g++) {
-        const unsigned long long todo = __ballot(!done);
-        if (todo == 0) break;
+    unsigned long long todo = __ballot(!done);
+    if (todo == 0) return acc;                                  // wave-uniform
+    {
+        // coherent wave: the 2x2x2 block of the first sampling lane serves everybody (lanes 0-7 fetch it)
         const int leader = __ffsll((long long)todo) - 1;
         const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
                   ck = __builtin_amdgcn_readlane(bk, leader);
         const bool mine = !done && bi == ci && bj == cj && bk == ck;
-        if (g > 0 && PHOTON_COOP_MIN_SHARE * __popcll(__ballot(mine)) < __popcll(todo)) break;       // see tex3d_cubic_coop
-        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-        if (!PHOTON_TILE_REUSE || key != tile_key) {            // wave-uniform: the 2x2x2 block is not parked yet
-            const int tx = clampi(ci + ta, 0, v.nx - 1), ty = clampi(cj + tb, 0, v.ny - 1),
-                      tz = clampi(ck + tc, 0, v.nz - 1);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 8) {
-                const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-                *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+        if (__ballot(mine) == todo) {                           // wave-uniform
+            const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
+            if (!PHOTON_TILE_REUSE || key != tile_key) {        // wave-uniform: the block is not parked yet
+                const int tx = clampi(ci + (lane & 1), 0, v.nx - 1), ty = clampi(cj + ((lane >> 1) & 1), 0, v.ny - 1),
+                          tz = clampi(ck + ((lane >> 2) & 1), 0, v.nz - 1);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 8) {
+                    const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+                    *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+                tile_key = key;
+            }
+            if (mine) {
+                // blk[tc*4 + tb*2 + ta]; same lerp tree as tex3d_linear
+                const f4 c00 = lerp4(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4(ldtexel(blk + 2), ldtexel(blk + 3), a);
+                const f4 c01 = lerp4(ldtexel(blk + 4), ldtexel(blk + 5), a), c11 = lerp4(ldtexel(blk + 6), ldtexel(blk + 7), a);
+                const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
+                acc = lerp4(c0, c1, c);
             }
             __builtin_amdgcn_wave_barrier();
-            tile_key = key;
+            return acc;
         }
-        if (mine) {
-            // blk[tc*4 + tb*2 + ta]; same lerp tree as tex3d_linear
-            const f4 c00 = lerp4(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4(ldtexel(blk + 2), ldtexel(blk + 3), a);
-            const f4 c01 = lerp4(ldtexel(blk + 4), ldtexel(blk + 5), a), c11 = lerp4(ldtexel(blk + 6), ldtexel(blk + 7), a);
+    }
+    // incoherent wave: bricks of 8x8x2 texels around the first unserved lane (two loads per lane); every lane
+    // whose block starts within [-3, +3] texels of it in x and y (same z) blends from there in one pass
+#pragma unroll 1
+    for (int pass = 0; pass < PHOTON_BRICK_PASSES && todo != 0; pass++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
+                  ck = __builtin_amdgcn_readlane(bk, leader);
+        const int di = bi - ci + 3, dj = bj - cj + 3;
+        const bool in_brick = !done && bk == ck && (unsigned)di <= 6u && (unsigned)dj <= 6u;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int t = lane + 64 * j;
+            const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
+                      tz = clampi(ck + (t >> 6), 0, v.nz - 1);
+            const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+            *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (in_brick) {
+            const f4 *q = brick + (dj * 8 + di);
+            const f4 c00 = lerp4(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4(ldtexel(q + 8), ldtexel(q + 9), a);
+            const f4 c01 = lerp4(ldtexel(q + 64), ldtexel(q + 65), a), c11 = lerp4(ldtexel(q + 72), ldtexel(q + 73), a);
             const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
             acc = lerp4(c0, c1, c);
             done = true;
         }
         __builtin_amdgcn_wave_barrier();
+        todo = __ballot(!done);
     }
     if (!done) acc = linear_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z, v.weight_scale);
     return acc;

@@ -277,7 +277,7 @@ template <int ALGO, int INTERP>
 __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *__restrict__ tex, int n,
                                                          float *__restrict__ pos, float *__restrict__ dir,
                                                          int *__restrict__ steps) {
-    __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
+    __shared__ f4 tiles[4][64 + 256];                                 // one 4x4x4 texel block per wave
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool has_ray = i < n;
     f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
@@ -348,7 +348,7 @@ template <int ALGO, int INTERP, bool SAVE>
 __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters,
                                                        NoiseDev noise, unsigned long long ray_base, InterDump idump) {
-    __shared__ f4 tiles[4][64];                                 // one 4x4x4 texel block per wave
+    __shared__ f4 tiles[4][64 + 256];                                 // one 4x4x4 texel block per wave
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
     const bool has_ray = r < n_rays;
