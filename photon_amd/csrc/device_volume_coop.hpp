@@ -97,13 +97,15 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     return acc;
 }
 
+// What is parked in the wave's LDS area (wave-uniform, kept by the marchers across samples): consecutive
+// samples of a ray advance by half a texel, so about every other sample finds its block / brick still there
+// and skips the fetch.
+struct Parked { int tile; int brick; };
+
 // Must be called by ALL 64 lanes of the wave (wave-uniform control flow); `need` says whether this
-// lane wants a sample.  blk = this wave's 64-texel LDS tile.
-// tile_key (wave-uniform, kept by the caller across samples) names the block currently parked in
-// the tile: consecutive samples of a ray advance by half a texel, so about every other sample finds
-// its block already there and skips the fetch.
+// lane wants a sample.  blk = this wave's LDS area: a 64-texel tile followed by a 256-texel brick.
 __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
-                                               float x, float y, float z, int &tile_key) {
+                                               float x, float y, float z, Parked &parked) {
     f4 *const brick = blk + 64;                                 // the wave's 8x8x4 brick follows its 4x4x4 tile
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
     const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
@@ -129,14 +131,14 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         if (__ballot(mine) == todo) {                           // wave-uniform
             // block id: base texels lie in [-1, n) per axis, so (c+1) fits n+1 values per axis
             const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-            if (!PHOTON_TILE_REUSE || key != tile_key) {        // wave-uniform (SALU compare)
+            if (!PHOTON_TILE_REUSE || key != parked.tile) {     // wave-uniform (SALU compare)
                 const int tx = clampi(ci - 1 + (lane & 3), 0, v.nx - 1), ty = clampi(cj - 1 + ((lane >> 2) & 3), 0, v.ny - 1),
                           tz = clampi(ck - 1 + (lane >> 4), 0, v.nz - 1);
                 const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));      // < 2^31 texels (checked on the host)
                 __builtin_amdgcn_wave_barrier();
                 *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
                 __builtin_amdgcn_wave_barrier();
-                tile_key = key;
+                parked.tile = key;
             }
             if (mine) acc = cubic_taps_lds<4, 16>(blk, wx, wy, wz);
             __builtin_amdgcn_wave_barrier();
@@ -155,16 +157,20 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                   ck = __builtin_amdgcn_readlane(bk, leader);
         const int di = bi - ci + 2, dj = bj - cj + 2;
         const bool in_brick = !done && bk == ck && (unsigned)di <= 4u && (unsigned)dj <= 4u;
-        __builtin_amdgcn_wave_barrier();
+        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
+        if (!PHOTON_TILE_REUSE || key != parked.brick) {        // wave-uniform
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int t = lane + 64 * j;
-            const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
-                      tz = clampi(ck - 1 + (t >> 6), 0, v.nz - 1);
-            const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-            *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+            for (int j = 0; j < 4; j++) {
+                const int t = lane + 64 * j;
+                const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
+                          tz = clampi(ck - 1 + (t >> 6), 0, v.nz - 1);
+                const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+                *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            parked.brick = key;
         }
-        __builtin_amdgcn_wave_barrier();
         if (in_brick) {
             acc = cubic_taps_lds<8, 64>(brick + (dj * 8 + di), wx, wy, wz);
             done = true;
@@ -188,7 +194,7 @@ __device__ __attribute__((noinline)) f4 linear_gather_fn(const f4 *__restrict__ 
 }
 
 __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
-                                                float x, float y, float z, int &tile_key) {
+                                                float x, float y, float z, Parked &parked) {
     f4 *const brick = blk + 64;                                 // 8x8x2 texels around the leader for incoherent waves
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
@@ -210,7 +216,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         const bool mine = !done && bi == ci && bj == cj && bk == ck;
         if (__ballot(mine) == todo) {                           // wave-uniform
             const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-            if (!PHOTON_TILE_REUSE || key != tile_key) {        // wave-uniform: the block is not parked yet
+            if (!PHOTON_TILE_REUSE || key != parked.tile) {     // wave-uniform: the block is not parked yet
                 const int tx = clampi(ci + (lane & 1), 0, v.nx - 1), ty = clampi(cj + ((lane >> 1) & 1), 0, v.ny - 1),
                           tz = clampi(ck + ((lane >> 2) & 1), 0, v.nz - 1);
                 __builtin_amdgcn_wave_barrier();
@@ -219,7 +225,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                     *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
                 }
                 __builtin_amdgcn_wave_barrier();
-                tile_key = key;
+                parked.tile = key;
             }
             if (mine) {
                 // blk[tc*4 + tb*2 + ta]; same lerp tree as tex3d_linear
@@ -241,16 +247,20 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                   ck = __builtin_amdgcn_readlane(bk, leader);
         const int di = bi - ci + 3, dj = bj - cj + 3;
         const bool in_brick = !done && bk == ck && (unsigned)di <= 6u && (unsigned)dj <= 6u;
-        __builtin_amdgcn_wave_barrier();
+        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
+        if (!PHOTON_TILE_REUSE || key != parked.brick) {        // wave-uniform
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int t = lane + 64 * j;
-            const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
-                      tz = clampi(ck + (t >> 6), 0, v.nz - 1);
-            const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-            *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+            for (int j = 0; j < 2; j++) {
+                const int t = lane + 64 * j;
+                const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
+                          tz = clampi(ck + (t >> 6), 0, v.nz - 1);
+                const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+                *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            parked.brick = key;
         }
-        __builtin_amdgcn_wave_barrier();
         if (in_brick) {
             const f4 *q = brick + (dj * 8 + di);
             const f4 c00 = lerp4(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4(ldtexel(q + 8), ldtexel(q + 9), a);
@@ -329,16 +339,16 @@ __device__ __forceinline__ void count_iterations(WaveCount &mc, bool yes) { mc.i
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
 template <int INTERP, class CNT>
 __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need, f3 lookup,
-                                          const f4 &val_prev, CNT &mc, int &tile_key) {
-    f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, tile_key)
-                         : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, tile_key);
+                                          const f4 &val_prev, CNT &mc, Parked &parked) {
+    f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked)
+                         : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked);
     count_samples(mc, need);
     if (INTERP == 1) {
         const float ambient = 1.000277;
         const bool low = need && val.w < v.data_min;
         const bool repair = low && val_prev.w == 0;
         if (__ballot(repair) != 0) {                            // wave-uniform, rare
-            const f4 t = tex3d_linear_coop(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, tile_key);
+            const f4 t = tex3d_linear_coop(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
             count_samples(mc, repair);
             if (repair) val = f4{t.x, t.y, t.z, ambient - 1};
         }
@@ -372,7 +382,8 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
                                          const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
                                          const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
-    int loop_ctr = 0, spins = 0, tile_key = -1;
+    int loop_ctr = 0, spins = 0;
+    Parked parked{-1, -1};
     f4 val_prev = f4{0, 0, 0, 0};
     f3 T_n = rdir, A = mk3(0, 0, 0), B = mk3(0, 0, 0), spos = rpos;     // only meaningful while `go`
     float delta_t = 0.f, current_n = 1.f;
@@ -396,7 +407,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
                 }
             }
         }
-        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
         bool go = false;                                        // lane continues to samples B and C
         if (need) {
             if (INTERP == 2 && val.w < u.data_min) {            // .h:1220-1227
@@ -421,7 +432,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1094-1101
             else need = true;
         }
-        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
         if (need) {
             val.w += 1;
             B = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
@@ -435,7 +446,7 @@ __device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const 
             if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1135-1141
             else need = true;
         }
-        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
         if (need) {
             val.w += 1;
             const f3 C = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
@@ -459,7 +470,8 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
                                            const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
                                            const GradNoise &gn, const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
-    int loop_ctr = 0, spins = 0, tile_key = -1;
+    int loop_ctr = 0, spins = 0;
+    Parked parked{-1, -1};
     f4 val_prev = f4{0, 0, 0, 0};
     while (__ballot(active) != 0) {
         bool need = false;
@@ -480,7 +492,7 @@ __device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, cons
                 }
             }
         }
-        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, tile_key);
+        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
         bool stepped = false;
         if (need) {
             if (INTERP == 1) {
