@@ -277,7 +277,7 @@ template <int ALGO, int INTERP>
 __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *__restrict__ tex, int n,
                                                          float *__restrict__ pos, float *__restrict__ dir,
                                                          int *__restrict__ steps) {
-    __shared__ f4 tiles[4][64 + 256];                                 // one 4x4x4 texel block per wave
+    __shared__ f4 tiles[4][64 + 256];                           // per wave: 4x4x4 tile + 8x8x4 brick (device_volume_coop.hpp)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool has_ray = i < n;
     f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
@@ -335,12 +335,11 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
     st.radiance[r] = ray.radiance;
 }
 
-// Stage 1b: march the rays through the volume, in place on the SoA state (world frame).  One lane
-// per ray, rays source-major so the 64 lanes of a wave start from (almost) the same point.
-// launch bound: 4 waves per SIMD (<= 128 VGPRs).  A wave issues at most one VALU instruction per
-// ~4 cycles, the SIMD one per 2: the march needs >= 3-4 resident waves to keep the VALU fed
-// (measured on C3 cubic: 142 VGPR / 3 waves 100.8 ms, 128 VGPR / 4 waves 93.2 ms, 96 VGPR / 5 waves
-// spills: 165 ms).
+// Stage 1b: march the rays through the volume, in place on the SoA state (world frame).  One lane per ray;
+// the launch's ray order (source-major / lens-major, SceneDev::ray_order) decides which rays share a wave.
+// Launch bound: 4 waves per SIMD (<= 128 VGPRs).  A wave issues at most one VALU instruction per ~4 cycles,
+// the SIMD one per 2: the march needs >= 3-4 resident waves to keep the VALU fed (measured on C3 cubic:
+// 3 waves 100.8 ms, 4 waves 93.2 ms at the time; 5 waves only with spills and no gain).
 #ifndef PHOTON_MARCH_WAVES
 #define PHOTON_MARCH_WAVES 4
 #endif
@@ -348,7 +347,7 @@ template <int ALGO, int INTERP, bool SAVE>
 __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters,
                                                        NoiseDev noise, unsigned long long ray_base, InterDump idump) {
-    __shared__ f4 tiles[4][64 + 256];                                 // one 4x4x4 texel block per wave
+    __shared__ f4 tiles[4][64 + 256];                           // per wave: 4x4x4 tile + 8x8x4 brick (device_volume_coop.hpp)
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
     const bool has_ray = r < n_rays;
