@@ -636,6 +636,40 @@ def test_in_library_device_sharding(photon, oracle, small_volume_file, monkeypat
     assert rel_l2(photon.render(call), single) <= IMAGE_TOL
 
 
+def test_api_misuse_is_reported_not_fatal(photon, capfd):
+    """Bad arguments to the extension entry points come back as non-zero return codes (raised as PhotonError by
+    the ctypes veneer), never as a crash, and leave no half-built handle behind."""
+    import ctypes
+    from photon_amd.library import PhotonError
+    L = photon.lib
+    h = ctypes.c_void_p()
+    assert L.photon_volume_load_nrrd(b"/nonexistent.nrrd", 1, ctypes.byref(h)) != 0 and not h.value
+    rho = np.ones((2, 2, 2), np.float32)                                    # fewer than 3 points per axis
+    with pytest.raises(PhotonError):
+        photon.volume_from_density(rho, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), 1)
+    with pytest.raises(PhotonError):
+        photon.volume_from_density(np.ones((4, 4, 4), np.float32), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), 3)   # unknown sampler
+    with pytest.raises(PhotonError):
+        photon.volume_gaussian(8, 1.0, (0, 0, 0), 1.0, 0.1, (0, 0, 0), 0.0, 1)                              # sigma = 0
+    with pytest.raises(PhotonError):
+        photon.sources_piv(1, -5, (0, 0, 0), (1, 1, 1), 0.0, 730.0, 1.0)                                    # negative count
+    with pytest.raises(PhotonError):
+        photon.sources_piv(1, 5, (0, 0, 0), (1, 1, 1), 0.0, 0.0, 1.0)                                       # beam width 0
+    with pytest.raises(PhotonError):
+        photon.sources_bos(np.zeros((2, 2)), np.zeros((0, 2)), 0.0, 1.0)                                    # empty template
+    assert L.photon_sources_count(None) == -1
+    vol = photon.volume_from_density(np.ones((4, 4, 4), np.float32), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), 1)
+    assert L.photon_volume_set_weight_bits(vol.handle, 40) != 0 and L.photon_volume_set_weight_bits(None, 8) != 0
+    call = scenes.bos_scene(n_dots=1, points_per_dot=2, rays_per_source=4)
+    scene = photon.scene_create(call)
+    assert L.photon_scene_set_ray_order(scene.handle, 7) != 0 and L.photon_scene_set_element_train(scene.handle, 2) != 0
+    img = np.zeros(call.image_shape, np.float32)
+    assert L.photon_trace(scene.handle, None, 0, 0, call.num_sources + 1, img.ctypes.data_as(ctypes.c_void_p), None, None) != 0
+    assert L.photon_trace(None, None, 0, 0, 0, None, None, None) != 0
+    scene.free(); vol.free()
+    assert "photon:" in capfd.readouterr().err
+
+
 def test_errors_leave_image_untouched(photon, small_volume_file, capfd):
     call = scenes.bos_scene(n_dots=2, points_per_dot=5, rays_per_source=8, density_grad_filename=small_volume_file)
     img = np.full(call.image_shape, 1.5, np.float32)
