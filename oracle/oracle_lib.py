@@ -39,7 +39,7 @@ def build_oracle(force: bool = False) -> str:
         for p in (src, os.path.join(ROOT, "include", "parallel_ray_tracing.h"),
                   os.path.join(ROOT, "include", "photon_det_math.h")))
     if force or stale:
-        subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+        subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True, stdout=sys.stderr)
     return ORACLE_SO
 
 

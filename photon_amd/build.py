@@ -57,8 +57,8 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
         return LIB_PATH
     cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB_PATH] + SOURCES
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(cmd), file=sys.stderr, flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC, stdout=sys.stderr)
     return LIB_PATH
 
 
