@@ -83,6 +83,14 @@ struct DumpDev {                    // ray dumps (save_lightrays), indexed by ch
 };
 
 enum { CNT_ON_SENSOR = 0, CNT_ITER = 1, CNT_SAMPLES = 2, CNT_TAPS = 3, CNT_N = 4 };
+// Statistics counters are kept in kCounterSlots copies (one 64-byte line each) and summed on the host: with one
+// copy every wave of a launch ends on an atomic to the SAME address, and 1.6e5 same-address device-scope atomics
+// serialise into ~2 ms -- more than the rest of the sensor stage (measured).
+constexpr int kCounterSlots = 1024;
+constexpr int kCounterStride = 8;       // u64 per slot: CNT_N used, padded to a cache line
+__device__ __forceinline__ unsigned long long *counter_slot(unsigned long long *counters) {
+    return counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride;
+}
 
 // Blocks b and b+8 share an XCD (round-robin dispatch); rays are ordered source-major, so giving
 // each XCD a contiguous range of logical blocks keeps rays that walk the same voxels on one L2.
@@ -365,8 +373,9 @@ __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDe
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
     }
     if ((threadIdx.x & 63) == 0) {
-        if (mc.iterations) atomicAdd(&counters[CNT_ITER], (unsigned long long)mc.iterations);
-        if (mc.samples) atomicAdd(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
+        unsigned long long *slot = counter_slot(counters);
+        if (mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)mc.iterations);
+        if (mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)mc.samples);
     }
 }
 
@@ -383,16 +392,19 @@ __global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigne
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
     }
-    wave_add(&counters[CNT_ITER], (unsigned long long)mc.iterations);
-    wave_add(&counters[CNT_SAMPLES], (unsigned long long)mc.samples);
+    wave_add(&counter_slot(counters)[CNT_ITER], (unsigned long long)mc.iterations);
+    wave_add(&counter_slot(counters)[CNT_SAMPLES], (unsigned long long)mc.samples);
 }
 
 // Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241).  FROM_STATE=false
 // (no density gradients) generates the ray in place, so that path is one fused kernel.
+#ifndef PHOTON_SPLIT_SENSOR
+#define PHOTON_SPLIT_SENSOR 1
+#endif
 #ifndef PHOTON_SENSOR_WAVES
 #define PHOTON_SENSOR_WAVES 2
 #endif
-template <bool FROM_STATE, bool TRAIN>
+template <bool FROM_STATE, bool TRAIN, bool SPLIT>
 __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
                                                      double *image, DumpDev dump, unsigned long long *counters) {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -454,9 +466,39 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
             dump.final_pos[3 * r] = fin.x; dump.final_pos[3 * r + 1] = fin.y; dump.final_pos[3 * r + 2] = fin.z;
         }
     }
-    taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req);      // all 64 lanes
-    wave_add(&counters[CNT_TAPS], (unsigned long long)taps);
-    wave_add(&counters[CNT_ON_SENSOR], (unsigned long long)on_sensor);
+    if (SPLIT) {
+        // hand the erf splat to splat_kernel through the (now consumed) state arrays: the optics above and the
+        // wave-cooperative splat below each want the register file to themselves
+        if (r < n_rays) {
+            st.px[r] = req.X; st.py[r] = req.Y; st.pz[r] = req.valid ? req.D : -1.f; st.dx[r] = req.rfD;
+            st.radiance[r] = req.scale;
+        }
+    } else {
+        taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req);  // all 64 lanes
+    }
+    wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
+    wave_add(&counter_slot(counters)[CNT_ON_SENSOR], (unsigned long long)on_sensor);
+}
+
+// Second half of the sensor stage for erf splats coming from the march (sensor_kernel<.., SPLIT=true>).
+__global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void splat_kernel(unsigned n_rays, RayStateDev st, double *image, int W, int H,
+                                                                         unsigned long long *counters) {
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    SplatReq req;
+    req.valid = false;
+    req.X = req.Y = req.D = req.rfD = 0.f; req.scale = 0.0; req.c0 = req.c1 = req.r0 = req.r1 = 0;
+    if (r < n_rays) {
+        const float D = st.pz[r];
+        if (D >= 0.f) {
+            req.valid = true;
+            req.X = st.px[r]; req.Y = st.py[r]; req.D = D; req.rfD = st.dx[r];
+            req.scale = st.radiance[r];
+            req.c0 = (int)floorf(req.X - req.rfD); req.c1 = (int)ceilf(req.X + req.rfD);     // erf_splat_prepare's window
+            req.r0 = (int)floorf(req.Y - req.rfD); req.r1 = (int)ceilf(req.Y + req.rfD);
+        }
+    }
+    const int taps = erf_splat_wave(image, W, H, req);                  // all 64 lanes
+    wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
 }
 
 // image_array is read-modify-write (parallel_ray_tracing.cu:3309,3675): fold the f64 accumulator of
@@ -1071,7 +1113,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         fprintf(stderr, "photon: sensor needs at least one pixel\n");
         return bail(1);
     }
-    hipError_t e = hipMalloc((void **)&s->d_counters, CNT_N * sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void **)&s->d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     e = hipMalloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
@@ -1233,11 +1275,21 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
 #undef PH_MARCH
         PH_CHECK(hipGetLastError());
         if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
-        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<true, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
-        else hipLaunchKernelGGL((sensor_kernel<true, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        // erf splats: optics and splat as two kernels (each gets the register file to itself); the 4-pixel
+        // splat is done in place by the first
+        const bool erf = PHOTON_SPLIT_SENSOR && (s->dev.cam.implement_diffraction || s->dev.elems[0].element_type == 'n');
+#define PH_SENSOR(T, S) hipLaunchKernelGGL((sensor_kernel<true, T, S>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters)
+        if (s->dev.train_mode) { if (erf) PH_SENSOR(true, true); else PH_SENSOR(true, false); }
+        else { if (erf) PH_SENSOR(false, true); else PH_SENSOR(false, false); }
+#undef PH_SENSOR
+        if (erf) {
+            PH_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(splat_kernel, grid, block, 0, stream, n, s->ws, d_image, s->dev.cam.x_pixel_number,
+                               s->dev.cam.y_pixel_number, s->d_counters);
+        }
     } else {
-        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<false, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
-        else hipLaunchKernelGGL((sensor_kernel<false, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<false, true, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        else hipLaunchKernelGGL((sensor_kernel<false, false, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     }
     PH_CHECK(hipGetLastError());
     return 0;
@@ -1256,7 +1308,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
     const long long max_sources = std::max<long long>(1, kMaxRaysPerLaunch / rps);
     if (rps > kMaxRaysPerLaunch) { fprintf(stderr, "photon: too many rays per source\n"); return 1; }
     if (stats) {
-        PH_CHECK(hipMemsetAsync(scene->d_counters, 0, CNT_N * sizeof(unsigned long long), stream));
+        PH_CHECK(hipMemsetAsync(scene->d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long), stream));
         PH_CHECK(hipEventRecord(scene->ev[0], stream));
     }
     float march_ms = 0.f;
@@ -1277,8 +1329,11 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
     if (stats) {
         PH_CHECK(hipEventRecord(scene->ev[3], stream));
         PH_CHECK(hipEventSynchronize(scene->ev[3]));
-        unsigned long long c[CNT_N];
-        PH_CHECK(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
+        PH_CHECK(hipMemcpy(slots.data(), scene->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long c[CNT_N] = {0, 0, 0, 0};
+        for (int k = 0; k < kCounterSlots; k++)
+            for (int j = 0; j < CNT_N; j++) c[j] += slots[(size_t)k * kCounterStride + j];
         memset(stats, 0, sizeof *stats);
         stats->rays_launched = (uint64_t)(src_end - src_begin) * rps;
         stats->rays_on_sensor = c[CNT_ON_SENSOR];
