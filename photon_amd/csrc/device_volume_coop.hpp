@@ -1,10 +1,11 @@
 // device_volume_coop.hpp - wave-cooperative, LDS-staged volume samplers and the RK4 march built
 // on them (the hot loop of the library).
 //
-// Why: rays are laid out source-major, so the 64 lanes of a wave start at one light-field source
-// and stay within a fraction of a texel of each other through the volume (ray_cone_pitch_ratio is
-// 1e-4 for BOS; a full PIV cone spreads over a few texels).  Nearly every sample of a wave needs the
-// SAME 4x4x4 (tricubic) / 2x2x2 (trilinear) texel block, only the weights differ per lane.  A
+// Why: a launch lays its rays out so that the 64 lanes of a wave travel together -- source-major for
+// narrow cones (BOS: ray_cone_pitch_ratio 1e-4, the rays of one source stay within a fraction of a texel
+// of each other), lens-major over spatially sorted sources for full-aperture cones (a patch a few texels
+// wide).  Nearly every sample of a coherent wave needs the SAME 4x4x4 (tricubic) / 2x2x2 (trilinear)
+// texel block, only the weights differ per lane; an incoherent one needs a small neighbourhood.  A
 // per-lane gather issues 64 x 64 16-byte loads for it and is bound by the vector-memory address
 // path (measured: 273 ms for 1e7 rays through 256^3).  Here instead:
 //
@@ -28,7 +29,6 @@
 #include "device_volume.hpp"
 
 namespace photon {
-
 
 #ifndef PHOTON_BRICK_PASSES
 #define PHOTON_BRICK_PASSES 6       // bricks parked per sample before the remaining lanes fall back to the per-lane gather
