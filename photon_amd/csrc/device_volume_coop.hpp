@@ -113,7 +113,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     bspline_weights(xg - fi, wx[0], wx[1], wx[2], wx[3]);
     bspline_weights(yg - fj, wy[0], wy[1], wy[2], wy[3]);
     bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
-    const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
+    const int bi = (int)fi, bj = (int)fj, bk = (int)fk;         // lanes that do not sample never lead and never match
     const int lane = threadIdx.x & 63;
     f4 acc = f4{0, 0, 0, 0};
     bool done = !need;
