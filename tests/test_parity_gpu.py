@@ -636,6 +636,34 @@ def test_in_library_device_sharding(photon, oracle, small_volume_file, monkeypat
     assert rel_l2(photon.render(call), single) <= IMAGE_TOL
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_scenes(photon, oracle, small_volume_file, monkeypatch, seed):
+    """A sweep over the knobs that decide which code path a wave takes -- rays per source around the wave size,
+    cone width from a micron to the full aperture (coherent tiles, bricks, gather), sampler, integrator, ray
+    order, BOS vs PIV sensor -- each case against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    rays = int(rng.choice([1, 2, 31, 63, 64, 65, 100, 257]))
+    ratio = float(rng.choice([1e-4, 1e-2, 0.1, 1.0]))
+    interp = int(rng.choice([1, 2]))
+    algorithm = int(rng.choice([1, 2]))
+    order = str(rng.choice(["source", "lens", "auto"]))
+    if rng.random() < 0.5:
+        call = scenes.bos_scene(n_dots=int(rng.integers(3, 12)), points_per_dot=int(rng.integers(5, 30)), rays_per_source=rays,
+                                density_grad_filename=small_volume_file, ray_tracing_algorithm=algorithm, seed=seed)
+    else:
+        call = scenes.piv_scene(n_particles=int(rng.integers(50, 600)), rays_per_source=rays, mie=bool(rng.integers(0, 2)),
+                                polydisperse=True, density_grad_filename=small_volume_file, field_half_width=2.5e4,
+                                ray_tracing_algorithm=algorithm, seed=seed)
+    call.ray_cone_pitch_ratio = ratio
+    monkeypatch.setenv("PHOTON_RAY_ORDER", order)
+    g, o, st = _render_both(photon, oracle, call, interp, monkeypatch)
+    assert st.rk_iterations > 0
+    if o.any():
+        assert rel_l2(g, o) <= IMAGE_TOL, (seed, rays, ratio, interp, algorithm, order, rel_l2(g, o))
+    else:
+        assert not g.any()
+
+
 def test_api_misuse_is_reported_not_fatal(photon, capfd):
     """Bad arguments to the extension entry points come back as non-zero return codes (raised as PhotonError by
     the ctypes veneer), never as a crash, and leave no half-built handle behind."""
