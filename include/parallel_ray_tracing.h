@@ -133,6 +133,7 @@ typedef struct camera_design_t {
  *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
  *                                reference seeds cuRAND with time(NULL); default 0x5eed)
  *   PHOTON_ELEMENT_TRAIN=reference|sequential   element-group walk (photon_scene_set_element_train)
+ *   PHOTON_SKIP_DOOMED=0|1       1 (default): rays that provably die on the first aperture are not marched
  *   PHOTON_RAY_ORDER=source|lens|auto           lane order of a launch (photon_scene_set_ray_order)
  *   PHOTON_DEVICES=all|0,1,..    shard the sources of one call over several GPUs (one host thread
  *                                and one private image per device, summed at the end); default:
@@ -256,6 +257,16 @@ int photon_scene_set_element_train(photon_scene_t *scene, int mode);
  * mode 1 or 2 the [src_begin, src_end) of photon_trace counts sources in the sorted order.
  * start_ray_tracing reads PHOTON_RAY_ORDER=source|lens|auto. */
 int photon_scene_set_ray_order(photon_scene_t *scene, int mode);
+
+/* Rays that cannot reach the sensor need not be marched (default on).  The reference kills a ray that meets the
+ * first element's front surface more than pitch/2 from the axis (thin lens .cu:447, thick lens .cu:560-566) --
+ * half of a full-aperture cone, whose lens samples reach out to a radius of one pitch (.cu:123-124) -- but only
+ * after marching it through the volume.  With the switch on, a ray whose UNDEFLECTED path misses the aperture by
+ * more than the largest footprint shift the volume can cause (bounded from the volume's largest |grad n|) is dropped
+ * before the march: same image, same rays_on_sensor; rk_iterations / volume_samples count only the rays marched.
+ * Off automatically for launches that write ray dumps, use gradient noise, integrators 3 / 4 or the element
+ * train.  start_ray_tracing reads PHOTON_SKIP_DOOMED=0|1. */
+int photon_scene_set_skip_doomed(photon_scene_t *scene, int on);
 
 /* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.

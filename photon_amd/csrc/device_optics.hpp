@@ -64,6 +64,9 @@ struct SceneDev {
     // coherent when the cone is as wide as the aperture (PIV through a volume).
     int ray_order;
     const int *src_perm;                // spatial order of the sources (lens-major only); nullptr = identity
+    // > 0: rays whose UNDEFLECTED path meets element 0's front surface more than pitch/2 + doom_margin from the
+    // axis are not marched (they are killed there whatever the volume does, .cu:560-566 / :447); 0 = off
+    float doom_margin;
 };
 
 // slot of this launch -> source index and lens-sample index; n_src = sources in this launch
@@ -253,6 +256,27 @@ __device__ __forceinline__ Ray single_element(const element_data_t &e, f3 center
     }
     ray.dir = dir; ray.pos = src; ray.wavelength = wavelength; ray.radiance = radiance;
     return ray;
+}
+
+// Distance from the optical axis at which a ray meets the front of element `e` -- the quantity the reference
+// tests against pitch/2 before anything else happens to the ray (thin lens .cu:440-447, thick lens .cu:540-566).
+// NaN when there is no such test for this element type (or no intersection): callers must treat NaN as
+// "cannot tell".
+__device__ __forceinline__ float front_axis_distance(const element_data_t &e, f3 center, const float *plane, const Ray &ray) {
+    const float a = plane[0], b = plane[1], c = plane[2], d = plane[3];
+    if (e.element_type == 't') {
+        const float t = -(dot(mk3(a, b, c), ray.pos) + d) / dot(mk3(a, b, c), ray.dir);
+        return axis_distance(ray.pos + ray.dir * t, center, plane);
+    }
+    if (e.element_type == 'l') {
+        const float Rf = e.element_geometry.front_surface_radius;
+        const double vertex_distance = e.element_geometry.vertex_distance;
+        const float nmag = sqrtf(a * a + b * b + c * c);
+        const float ds = (float)(+vertex_distance / 2.0 - Rf);
+        const f3 c_front = center + mk3(a, b, c) * ds / nmag;
+        return axis_distance(ray_sphere_intersection(c_front, Rf, ray.dir, ray.pos), center, plane);
+    }
+    return nanf("");
 }
 
 // The WORKING element train (train_mode 1; the reference advertises it, its device code is a stub and

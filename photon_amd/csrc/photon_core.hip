@@ -92,13 +92,20 @@ __device__ __forceinline__ unsigned long long *counter_slot(unsigned long long *
     return counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride;
 }
 
-// Blocks b and b+8 share an XCD (round-robin dispatch); rays are ordered source-major, so giving
-// each XCD a contiguous range of logical blocks keeps rays that walk the same voxels on one L2.
-// Bijective for any grid size.  Speed only -- never correctness.
+// Blocks b and b+8 share an XCD (round-robin dispatch).  Rays that walk the same voxels should meet in one L2,
+// so each XCD gets whole CHUNKS of PHOTON_XCD_CHUNK consecutive logical blocks (8 K rays: some dozen neighbouring
+// sources); the chunks themselves are dealt round-robin, which keeps the eight XCDs evenly loaded when the work
+// per ray varies along the launch (lens-major launches: whole lens samples may be skipped as doomed).
+// Bijective for any grid size (the ragged tail is left in place).  Speed only -- never correctness.
+#ifndef PHOTON_XCD_CHUNK
+#define PHOTON_XCD_CHUNK 32
+#endif
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
-    const unsigned q = nb >> 3, rem = nb & 7u, xcd = bid & 7u, idx = bid >> 3;
-    const unsigned start = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    return start + idx;
+    constexpr unsigned B = PHOTON_XCD_CHUNK;
+    const unsigned full = nb / (8u * B) * (8u * B);            // blocks that form complete rounds of 8 chunks
+    if (bid >= full) return bid;
+    const unsigned xcd = bid & 7u, q = bid >> 3;                // q-th block this XCD receives
+    return ((q / B) * 8u + xcd) * B + q % B;
 }
 
 __device__ __forceinline__ void wave_add(unsigned long long *dst, unsigned long long v) {
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void build_volume_kernel(const float *__restri
     const size_t n = (size_t)W * H * D;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float K = 0.225e-3;
-    float mine = FLT_MAX;
+    float mine = FLT_MAX, gmag = 0.f;
     if (i < n) {
         const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((size_t)W * H));
         const size_t WH = (size_t)W * H;
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(256) void build_volume_kernel(const float *__restri
         const float w = d(x, y, z);
         *reinterpret_cast<float4 *>(out + i) = make_float4(nxv, nyv, nzv, w);
         mine = w;
+        gmag = sqrtf(nxv * nxv + nyv * nyv + nzv * nzv);
     }
     // block minimum of n-1 (data_min, .h:1868-1869)
     __shared__ float red[256];
@@ -169,6 +177,15 @@ __global__ __launch_bounds__(256) void build_volume_kernel(const float *__restri
         __syncthreads();
     }
     if (threadIdx.x == 0) block_min[blockIdx.x] = red[0];
+    // block maximum of |grad n| (bounds how far the volume can bend a ray: launch_chunk's doom margin)
+    __syncthreads();
+    red[threadIdx.x] = gmag == gmag ? gmag : 0.f;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_min[gridDim.x + blockIdx.x] = red[0];
 }
 
 // rho[k][j][i] = rho0 + amp * gz[k] * (gy[j] * gx[i]) in double, rounded once to f32 (the order of the
@@ -338,6 +355,14 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
     p.z = (float)(p.z - (sc.z_offset + 750e3));                         // .cu:2045
     p = matvec(sc.cam.inverse_rotation_matrix, p);                      // camera -> world
     d = matvec(sc.cam.inverse_rotation_matrix, d);
+    if (sc.doom_margin > 0.f) {
+        // aimed so far outside the first element's aperture that no deflection the volume can produce brings it
+        // back (margin from the volume's largest gradient, launch_chunk): dead on arrival -- mark it, the march
+        // skips it, the sensor stage drops it as it would after the lens.  Half of a full-aperture PIV cone.
+        const float dist = front_axis_distance(sc.elems[0], mk3(sc.centers[0][0], sc.centers[0][1], sc.centers[0][2]),
+                                               sc.planes[0], ray);
+        if (dist > sc.elems[0].element_geometry.pitch / 2.0 + sc.doom_margin) p = nan3();
+    }
     st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
     st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
     st.radiance[r] = ray.radiance;
@@ -361,14 +386,16 @@ __global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDe
     const bool has_ray = r < n_rays;
     WaveCount mc{0u, 0u};                                       // wave-uniform totals (SGPRs)
     f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
+    bool marching = has_ray;
     if (has_ray) {
         p = mk3(st.px[r], st.py[r], st.pz[r]);
         d = mk3(st.dx[r], st.dy[r], st.dz[r]);
+        marching = !isnan3(p);                                  // rays marked dead by raygen_kernel stay out of the march
     }
     const GradNoise gn{noise.add_ngrad, noise.ngrad_std, noise.seed, ray_base + r};
     idump.ray = r;                                              // chunk-global ray id, like the final dumps
-    trace_volume_coop<ALGO, INTERP, SAVE, WaveCount>(has_ray, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
-    if (has_ray) {
+    trace_volume_coop<ALGO, INTERP, SAVE, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
+    if (marching) {
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
     }
@@ -388,9 +415,11 @@ __global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigne
     if (r < n_rays) {
         f3 p = mk3(st.px[r], st.py[r], st.pz[r]);
         f3 d = mk3(st.dx[r], st.dy[r], st.dz[r]);
-        trace_volume_extra<ALGO>(p, d, vol, mc);
-        st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
-        st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+        if (!isnan3(p)) {
+            trace_volume_extra<ALGO>(p, d, vol, mc);
+            st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
+            st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+        }
     }
     wave_add(&counter_slot(counters)[CNT_ITER], (unsigned long long)mc.iterations);
     wave_add(&counter_slot(counters)[CNT_SAMPLES], (unsigned long long)mc.samples);
@@ -513,6 +542,7 @@ __global__ __launch_bounds__(256) void finalize_image_kernel(float *__restrict__
 // host: handles
 // =============================================================================================
 struct photon_volume {
+    float grad_max = 0.f;               // largest |grad n| of the texels (per micron)
     VolumeDev dev{};
     photon_volume_info_t info{};
     f4 *d_texels = nullptr;
@@ -535,6 +565,7 @@ struct photon_scene {
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int ray_order_mode = 2;             // 0 source-major, 1 lens-major, 2 auto (photon_scene_set_ray_order)
+    bool skip_doomed = true;            // photon_scene_set_skip_doomed
     float lens_z = 0.f;                 // element 0's centre, for the auto rule
     int *d_perm = nullptr;              // spatial (Morton) order of the sources, built on first lens-major launch
 };
@@ -734,7 +765,7 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
 #define PH_VCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fprintf(stderr, "photon: HIP error %d (%s) at %s:%d\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); return fail((int)_e); } } while (0)
     PH_VCHECK(hipMalloc((void **)&v->d_texels, n * sizeof(f4)));
     PH_VCHECK(hipMalloc((void **)&d_rho, n * sizeof(float)));
-    PH_VCHECK(hipMalloc((void **)&d_min, blocks * sizeof(float)));
+    PH_VCHECK(hipMalloc((void **)&d_min, 2 * (size_t)blocks * sizeof(float)));      // block minima of n-1 | block maxima of |grad n|
     if (src.host_rho) {
         PH_VCHECK(hipMemcpy(d_rho, src.host_rho, n * sizeof(float), hipMemcpyHostToDevice));
     } else {
@@ -746,10 +777,14 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
     hipLaunchKernelGGL(build_volume_kernel, dim3(blocks), dim3(256), 0, 0, d_rho, nx, ny, nz, gx, gy, gz, v->d_texels,
                        d_min);
     PH_VCHECK(hipGetLastError());
-    std::vector<float> mins(blocks);
-    PH_VCHECK(hipMemcpy(mins.data(), d_min, blocks * sizeof(float), hipMemcpyDeviceToHost));
-    float data_min = FLT_MAX;
-    for (float m : mins) if (m < data_min) data_min = m;
+    std::vector<float> mins(2 * (size_t)blocks);
+    PH_VCHECK(hipMemcpy(mins.data(), d_min, mins.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float data_min = FLT_MAX, grad_max = 0.f;
+    for (unsigned k = 0; k < blocks; k++) {
+        if (mins[k] < data_min) data_min = mins[k];
+        if (mins[blocks + k] > grad_max) grad_max = mins[blocks + k];
+    }
+    v->grad_max = grad_max;
     if (interpolation == 2) {
         PH_VCHECK(hipMalloc((void **)&v->d_coeffs, n * sizeof(f4)));
         PH_VCHECK(hipMemcpy(v->d_coeffs, v->d_texels, n * sizeof(f4), hipMemcpyDeviceToDevice));
@@ -1101,6 +1136,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         d.train_mode = 0;
         d.ray_order = 0;
         d.src_perm = nullptr;
+        d.doom_margin = 0.f;
         s->lens_z = (float)element_center[0][2];
         if ((rc = upload(s, edp, (size_t)num_elements, &d.all_elems))) return bail(rc);
         if ((rc = upload(s, centers.data(), centers.size(), &d.all_centers))) return bail(rc);
@@ -1142,6 +1178,12 @@ int photon_scene_set_element_train(photon_scene_t *s, int mode) {
 int photon_scene_set_ray_order(photon_scene_t *s, int mode) {
     if (!s || mode < 0 || mode > 2) return 1;
     s->ray_order_mode = mode;
+    return 0;
+}
+
+int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {
+    if (!s) return 1;
+    s->skip_doomed = on != 0;
     return 0;
 }
 
@@ -1236,6 +1278,44 @@ static bool use_lens_major(const photon_scene *s, const photon_volume *vol, cons
     return cone > texel;
 }
 
+// Rays that cannot reach the sensor need not be marched.  The reference kills a ray whose intersection with the
+// first element's front surface lies more than pitch/2 from the axis (.cu:447, 560-566) -- for a full-aperture
+// cone that is half of all rays, because the lens-sample radius goes up to pitch, not pitch/2 (.cu:123-124).
+// The volume only bends a ray by a bounded angle: |d(n t)/ds| = |grad n| <= G, so after a path of length L inside
+// the volume its direction is off by at most G L / n_min, and its footprint on the lens by at most that angle times
+// the distance still to go (plus the walk-off inside the volume).  Returns that bound, times a safety factor
+// that also covers the tricubic sampler's overshoot and the integrator's error, plus a thousandth of the
+// aperture; 0 when the skip does not apply.
+static float doom_margin(const photon_scene *s, const photon_volume *vol, int algorithm, const DumpDev &dump) {
+    if (!s->skip_doomed || !vol || (algorithm != 1 && algorithm != 2) || dump.final_pos || dump.inter_pos) return 0.f;
+    if (s->dev.train_mode != 0 || s->dev.noise.add_ngrad) return 0.f;
+    const char type = s->dev.elems[0].element_type;
+    if (type != 'l' && type != 't') return 0.f;
+    // the reference path applies element 0 once per single-member group: there must be one
+    bool applied = false;
+    const int n = std::min(s->dev.num_elements, kMaxElements);
+    int seq = 0;
+    for (int k = 0; k < n; k++) seq = std::max(seq, s->dev.sys_index[k]);
+    for (int idx = 0; idx < seq && !applied; idx++) {
+        int count = 0;
+        for (int k = 0; k < n; k++) count += (seq - s->dev.sys_index[k] == idx);
+        applied = count == 1;
+    }
+    if (!applied) return 0.f;
+    const VolumeDev &v = vol->dev;
+    const double ex = (double)v.max_bound.x - v.min_bound.x, ey = (double)v.max_bound.y - v.min_bound.y,
+                 ez = (double)v.max_bound.z - v.min_bound.z;
+    const double L = sqrt(ex * ex + ey * ey + ez * ez);
+    const double n_min = 1.0 + std::min(0.0, (double)v.data_min);
+    const double angle = (double)vol->grad_max * L / n_min;
+    const double z_obj = (double)s->dev.object_distance + s->dev.z_offset;
+    const double to_lens = fabs(z_obj - s->lens_z) + L;                 // generous: the whole object-lens distance
+    const double pitch = s->dev.elems[0].element_geometry.pitch;
+    const double margin = 8.0 * angle * (to_lens + L) + 1e-3 * pitch;
+    if (!(margin == margin) || !(pitch > 0)) return 0.f;
+    return (float)margin;
+}
+
 static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
                         long long src_end, DumpDev dump, hipStream_t stream, bool timed) {
     double *d_image = s->d_acc;
@@ -1244,6 +1324,7 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     if (n64 > kMaxRaysPerLaunch) return 1;
     const unsigned n = (unsigned)n64;
     const dim3 block(256), grid((n + 255) / 256);
+    s->dev.doom_margin = doom_margin(s, vol, algorithm, dump);
     s->dev.ray_order = 0;
     s->dev.src_perm = nullptr;
     if (use_lens_major(s, vol, dump)) {
@@ -1374,6 +1455,12 @@ int interpolation_from_env() {
 int element_train_from_env() {
     const char *e = getenv("PHOTON_ELEMENT_TRAIN");
     return e && (strcmp(e, "sequential") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
+}
+
+// PHOTON_SKIP_DOOMED=0 marches every ray like the reference does (photon_scene_set_skip_doomed)
+int skip_doomed_from_env() {
+    const char *e = getenv("PHOTON_SKIP_DOOMED");
+    return !(e && strcmp(e, "0") == 0);
 }
 
 // PHOTON_RAY_ORDER=source|lens|auto (photon_scene_set_ray_order)
@@ -1508,6 +1595,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                                                ngrad_noise_std, seed);
                         photon_scene_set_element_train(sc, element_train_from_env());
                         photon_scene_set_ray_order(sc, ray_order_from_env());
+                        photon_scene_set_skip_doomed(sc, skip_doomed_from_env());
                         photon_volume *v = nullptr;
                         float *d_img = nullptr;
                         int rc = 0;
@@ -1579,6 +1667,7 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
                                ngrad_noise_std, seed);
         photon_scene_set_element_train(scene, element_train_from_env());
         photon_scene_set_ray_order(scene, ray_order_from_env());
+        photon_scene_set_skip_doomed(scene, skip_doomed_from_env());
     }
     photon_volume *vol = nullptr;
     if (simulate_density_gradients) {

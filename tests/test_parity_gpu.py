@@ -636,6 +636,47 @@ def test_in_library_device_sharding(photon, oracle, small_volume_file, monkeypat
     assert rel_l2(photon.render(call), single) <= IMAGE_TOL
 
 
+def test_doomed_rays_are_skipped_not_missed(photon, oracle, small_volume_file, monkeypatch):
+    """photon_scene_set_skip_doomed / PHOTON_SKIP_DOOMED: rays aimed outside the first aperture by more than the
+    volume can bend them back are dropped before the march.  Image and rays_on_sensor must not change (thick and
+    thin lens, both ray orders); the march does visibly less work for a full-aperture cone and exactly the same
+    for a BOS cone (nothing doomed)."""
+    import torch
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    vol = photon.volume_load_nrrd(small_volume_file, 2)
+    for lens_model in ("general", "thin-lens"):
+        call = scenes.piv_scene(n_particles=500, rays_per_source=64, mie=False, density_grad_filename=small_volume_file,
+                                field_half_width=2.5e4, seed=9)
+        if lens_model == "thin-lens":
+            geom = scenes.single_lens_camera(lens_model="thin-lens", **scenes.SAMPLE_LENS)
+            call.elements = [geom["element"]]
+        o, ost = oracle.render(call, interpolation=2)
+        H, W = call.image_shape
+        scene = photon.scene_create(call)
+        res = {}
+        for skip in (0, 1):
+            for order in (0, 1):
+                scene.set_skip_doomed(skip)
+                scene.set_ray_order(order)
+                img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+                st = scene.trace(img.data_ptr(), vol, 2, want_stats=True)
+                res[(skip, order)] = (img.cpu().numpy().reshape(H, W), st)
+                assert rel_l2(res[(skip, order)][0], o) <= IMAGE_TOL, (lens_model, skip, order)
+                assert st.rays_on_sensor == ost.rays_on_sensor
+        assert res[(0, 0)][1].rk_iterations == ost.rk_iterations
+        assert res[(1, 0)][1].rk_iterations < 0.9 * ost.rk_iterations           # a good part of the cone is doomed
+        assert res[(1, 1)][1].rk_iterations == res[(1, 0)][1].rk_iterations
+        scene.free()
+    bos = scenes.bos_scene(n_dots=5, points_per_dot=20, rays_per_source=100, density_grad_filename=small_volume_file)
+    scene = photon.scene_create(bos)
+    img = torch.zeros(bos.image_shape[0] * bos.image_shape[1], dtype=torch.float32, device="cuda")
+    _, ost = oracle.render(bos, interpolation=2)
+    assert scene.trace(img.data_ptr(), vol, 2, want_stats=True).rk_iterations == ost.rk_iterations
+    scene.free(); vol.free()
+    monkeypatch.setenv("PHOTON_SKIP_DOOMED", "0")                         # the ABI path takes the switch from the environment
+    assert rel_l2(photon.render(call), o) <= IMAGE_TOL
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_randomised_scenes(photon, oracle, small_volume_file, monkeypatch, seed):
     """A sweep over the knobs that decide which code path a wave takes -- rays per source around the wave size,

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="C2,C3lin,C3,C5")
     ap.add_argument("--ray-order", type=int, default=2)
+    ap.add_argument("--skip-doomed", type=int, default=1)
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
@@ -34,6 +35,7 @@ def main():
         call = scenes.config(base, work, scale=scale) if base != "C2" else scenes.config("C2")
         scene = lib.scene_create(call)
         scene.set_ray_order(args.ray_order)
+        scene.set_skip_doomed(args.skip_doomed)
         vol = lib.volume_load_nrrd(call.density_grad_filename, interp) if call.simulate_density_gradients else None
         H, W = call.image_shape
         img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
