@@ -179,6 +179,29 @@ def test_reference_sample_inputs(photon, oracle, case, monkeypatch):
     assert rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
 
 
+@pytest.mark.parametrize("case", ["piv", "bos_im1", "bos_im2"])
+def test_sample_tiff_pixel_arrays(photon, oracle, case, tmp_path, monkeypatch):
+    """The north star's acceptance sentence: the OUTPUT TIFF pixel arrays of the sample PIV and BOS cases.  Both
+    raw images go through photon's sensor post-processing (gain, normalise to the brightest pixel, round to the
+    sensor's bit depth, stretch to 16 bit; perform_ray_tracing_03.py:2190-2247) and the TIFF writer; the uint16
+    arrays read back from the files must agree: a pixel may flip to the neighbouring grey level only where the
+    1e-6-level difference of the raw images straddles a rounding boundary."""
+    from photon_amd.ray_tracing import postprocess_image, read_tiff_u16, write_tiff_u16
+    call = load_fixture_call(case)
+    g, o, _ = _render_both(photon, oracle, call, 1, monkeypatch)
+    cam = call.camera
+    levels = {}
+    for tag, raw in (("gpu", g), ("cpu", o)):
+        img = postprocess_image(raw, cam["pixel_gain"], cam["pixel_bit_depth"])
+        path = write_tiff_u16(str(tmp_path / f"{case}_{tag}.tif"), img)
+        levels[tag] = read_tiff_u16(path).astype(np.int64)
+    step = 65535 // (2 ** int(cam["pixel_bit_depth"]) - 1)                 # one grey level of the sensor in 16-bit counts
+    diff = np.abs(levels["gpu"] - levels["cpu"])
+    assert levels["cpu"].max() == 65535 and levels["cpu"].any()
+    assert diff.max() <= step + 1, diff.max()
+    assert (diff > 0).mean() <= 1e-4, (diff > 0).mean()
+
+
 def test_c0_plumbing(photon, oracle):
     call = scenes.config("C0")
     g, o, st = _render_both(photon, oracle, call)
