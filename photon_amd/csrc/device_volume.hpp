@@ -311,41 +311,50 @@ __device__ __forceinline__ void euler(f3 &rpos, f3 &rdir, const VolumeDev &v, f3
 // Per-lane building blocks shared with the wave-cooperative samplers (device_volume_coop.hpp).
 // =============================================================================================
 
-// The 64-tap separable sum with per-lane, clamped addressing (incoherent waves).  Deliberately
-// NOT inlined: it is the rare path, and inlined at three call sites its 64 loads in flight would
-// set the register budget (and so the occupancy) of the whole march kernel.
-// (It recomputes the B-spline weights from the coordinate -- same operations, same values -- so a
-// call site only has to pass three floats.)
+// The 64-tap separable sum with per-lane, clamped addressing (stragglers of incoherent waves).  Deliberately
+// NOT inlined: it is the rare path, and inlined at three call sites it would set the register budget (and so
+// the occupancy) of the whole march kernel.  It recomputes the B-spline weights from the coordinate -- same
+// operations, same values -- so a call site only has to pass three floats.
+// One of the four B-spline weights of bspline_weights(f, ...), selected at run time (same operations, same
+// values): lets the rolled loops below keep a single weight in registers instead of three arrays.
+__device__ __forceinline__ float bspline_weight_at(float f, int idx) {
+    float w0, w1, w2, w3;
+    bspline_weights(f, w0, w1, w2, w3);
+    return idx == 0 ? w0 : idx == 1 ? w1 : idx == 2 ? w2 : w3;
+}
+
+// Written for the SMALLEST register footprint, not for speed: every loop rolled, one texel in flight, weights
+// recomputed where they are used.  Under the AMDGPU calling convention a kernel's values that live across a
+// call sit above the callee's registers, so this function's count adds to the caller's: at 81 VGPRs (the first
+// version) it alone pushed the march kernels past the 96 of five waves per SIMD.
 __device__ __attribute__((noinline)) f4 cubic_gather_fn(const f4 *__restrict__ tex, int nx, int ny, int nz, float x,
                                                         float y, float z) {
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
     const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
-    float wx[4], wy[4], wz[4];
-    bspline_weights(xg - fi, wx[0], wx[1], wx[2], wx[3]);
-    bspline_weights(yg - fj, wy[0], wy[1], wy[2], wy[3]);
-    bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
+    const float fx = xg - fi, fy = yg - fj, fz = zg - fk;
     const int i = (int)fi, j = (int)fj, k = (int)fk;
-    const size_t W = nx, WH = (size_t)nx * ny;
     f4 acc = f4{0, 0, 0, 0};
 #pragma unroll 1
-    for (int c = 0; c < 4; c++) {                       // rolled: small register footprint
-        const f4 *slab = tex + clampi(k - 1 + c, 0, nz - 1) * WH;
+    for (int c = 0; c < 4; c++) {
+        const unsigned slab = (unsigned)clampi(k - 1 + c, 0, nz - 1) * (unsigned)ny;
         f4 plane = f4{0, 0, 0, 0};
 #pragma unroll 1
         for (int b = 0; b < 4; b++) {
-            const f4 *row = slab + clampi(j - 1 + b, 0, ny - 1) * W;
-            const f4 t0 = ldtexel(row + clampi(i - 1, 0, nx - 1)), t1 = ldtexel(row + clampi(i, 0, nx - 1));
-            const f4 t2 = ldtexel(row + clampi(i + 1, 0, nx - 1)), t3 = ldtexel(row + clampi(i + 2, 0, nx - 1));
-            f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
-            r = f4{fmaf(wx[1], t1.x, r.x), fmaf(wx[1], t1.y, r.y), fmaf(wx[1], t1.z, r.z), fmaf(wx[1], t1.w, r.w)};
-            r = f4{fmaf(wx[2], t2.x, r.x), fmaf(wx[2], t2.y, r.y), fmaf(wx[2], t2.z, r.z), fmaf(wx[2], t2.w, r.w)};
-            r = f4{fmaf(wx[3], t3.x, r.x), fmaf(wx[3], t3.y, r.y), fmaf(wx[3], t3.z, r.z), fmaf(wx[3], t3.w, r.w)};
-            const float wyb = wy[b];
+            const unsigned row = (slab + (unsigned)clampi(j - 1 + b, 0, ny - 1)) * (unsigned)nx;
+            f4 r = f4{0, 0, 0, 0};
+#pragma unroll 1
+            for (int a = 0; a < 4; a++) {
+                const f4 t = ldtexel(tex + (row + (unsigned)clampi(i - 1 + a, 0, nx - 1)));
+                const float w = bspline_weight_at(fx, a);
+                if (a == 0) r = f4{w * t.x, w * t.y, w * t.z, w * t.w};
+                else r = f4{fmaf(w, t.x, r.x), fmaf(w, t.y, r.y), fmaf(w, t.z, r.z), fmaf(w, t.w, r.w)};
+            }
+            const float wyb = bspline_weight_at(fy, b);
             if (b == 0) plane = f4{wyb * r.x, wyb * r.y, wyb * r.z, wyb * r.w};
             else plane = f4{fmaf(wyb, r.x, plane.x), fmaf(wyb, r.y, plane.y), fmaf(wyb, r.z, plane.z),
                             fmaf(wyb, r.w, plane.w)};
         }
-        const float wzc = wz[c];
+        const float wzc = bspline_weight_at(fz, c);
         if (c == 0) acc = f4{wzc * plane.x, wzc * plane.y, wzc * plane.z, wzc * plane.w};
         else acc = f4{fmaf(wzc, plane.x, acc.x), fmaf(wzc, plane.y, acc.y), fmaf(wzc, plane.z, acc.z),
                       fmaf(wzc, plane.w, acc.w)};

@@ -370,17 +370,17 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 
 // Stage 1b: march the rays through the volume, in place on the SoA state (world frame).  One lane per ray;
 // the launch's ray order (source-major / lens-major, SceneDev::ray_order) decides which rays share a wave.
-// Launch bound: 4 waves per SIMD (<= 128 VGPRs).  A wave issues at most one VALU instruction per ~4 cycles,
-// the SIMD one per 2: the march needs >= 3-4 resident waves to keep the VALU fed (measured on C3 cubic:
-// 3 waves 100.8 ms, 4 waves 93.2 ms at the time; 5 waves only with spills and no gain).
+// Launch bound: 5 waves per SIMD (<= 96 VGPRs).  A wave issues at most one VALU instruction per ~4 cycles, the
+// SIMD one per 2, and every wave spends part of its time waiting on LDS: the more resident waves the better
+// (C3 tricubic: 3 waves 100.8 ms, 4 waves 93.2 ms at the time; now 4 waves 68.8, 5 waves 67.1 ms; trilinear 28.0
+// -> 25.1 ms).  What made 96 registers reachable was the out-of-line gather fallback: under the AMDGPU calling
+// convention the caller's live values sit ABOVE the callee's registers, so its 81 VGPRs were part of the march
+// kernels' budget until it was rewritten to need 51 (device_volume.hpp).
 #ifndef PHOTON_MARCH_WAVES
-#define PHOTON_MARCH_WAVES 4
-#endif
-#ifndef PHOTON_MARCH_WAVES_LINEAR
-#define PHOTON_MARCH_WAVES_LINEAR 5     // the trilinear march needs < 96 VGPRs: one more wave per SIMD (C3: 28.0 -> 25.2 ms)
+#define PHOTON_MARCH_WAVES 5
 #endif
 template <int ALGO, int INTERP, bool SAVE>
-__global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
+__global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters,
                                                        NoiseDev noise, unsigned long long ray_base, InterDump idump) {
     __shared__ f4 tiles[4][64 + 256];                           // per wave: 4x4x4 tile + 8x8x4 brick (device_volume_coop.hpp)
