@@ -67,21 +67,23 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     float wx0 = wx[0];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        if (r + PHOTON_LDS_AHEAD < 16) {
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-                t[(r + PHOTON_LDS_AHEAD) % D][a] = ldtexel(blk + ((r + PHOTON_LDS_AHEAD) >> 2) * SS + ((r + PHOTON_LDS_AHEAD) & 3) * RS + a);
-        }
-        // the row's FMAs start from wx0: routing it through the barrier keeps them BELOW the reads just
-        // issued (ALU instructions are otherwise free to move above a memory barrier, which shrinks the
-        // read-ahead distance to a fraction of a row)
-        asm volatile("" : "+v"(wx0) : : "memory");
+        // one read of row r+AHEAD, then one tap (4 FMAs) of row r, four times: the reads reach the LDS pipe spread
+        // out instead of in bursts of four.  The row's FMAs start from wx0: routing it through the barrier keeps
+        // them BELOW the read just issued (ALU instructions are otherwise free to move above a memory barrier,
+        // which shrinks the read-ahead distance)
         const int b = r & 3, c = r >> 2;
-        const f4 t0 = t[r % D][0], t1 = t[r % D][1], t2 = t[r % D][2], t3 = t[r % D][3];
-        f4 q = f4{wx0 * t0.x, wx0 * t0.y, wx0 * t0.z, wx0 * t0.w};
-        q = f4{fmaf(wx[1], t1.x, q.x), fmaf(wx[1], t1.y, q.y), fmaf(wx[1], t1.z, q.z), fmaf(wx[1], t1.w, q.w)};
-        q = f4{fmaf(wx[2], t2.x, q.x), fmaf(wx[2], t2.y, q.y), fmaf(wx[2], t2.z, q.z), fmaf(wx[2], t2.w, q.w)};
-        q = f4{fmaf(wx[3], t3.x, q.x), fmaf(wx[3], t3.y, q.y), fmaf(wx[3], t3.z, q.z), fmaf(wx[3], t3.w, q.w)};
+        const int rn = r + PHOTON_LDS_AHEAD;
+        f4 q = f4{0, 0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if (rn < 16) t[rn % D][a] = ldtexel(blk + (rn >> 2) * SS + (rn & 3) * RS + a);
+            asm volatile("" : "+v"(wx0) : : "memory");
+            const f4 ta = t[r % D][a];
+            const float w = a == 0 ? wx0 : wx[a];
+            if (a == 0) q = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
+            else q = f4{fmaf(w, ta.x, q.x), fmaf(w, ta.y, q.y), fmaf(w, ta.z, q.z), fmaf(w, ta.w, q.w)};
+            if (a < 3) asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w) : : "memory");
+        }
         if (b == 0) plane = f4{wy[0] * q.x, wy[0] * q.y, wy[0] * q.z, wy[0] * q.w};
         else plane = f4{fmaf(wy[b], q.x, plane.x), fmaf(wy[b], q.y, plane.y), fmaf(wy[b], q.z, plane.z),
                         fmaf(wy[b], q.w, plane.w)};
