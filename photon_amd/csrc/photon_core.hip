@@ -379,8 +379,11 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #ifndef PHOTON_MARCH_WAVES
 #define PHOTON_MARCH_WAVES 5
 #endif
+#ifndef PHOTON_MARCH_WAVES_LINEAR
+#define PHOTON_MARCH_WAVES_LINEAR 6     // the trilinear kernels are small enough for a sixth wave
+#endif
 template <int ALGO, int INTERP, bool SAVE>
-__global__ __launch_bounds__(256, PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
+__global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters,
                                                        NoiseDev noise, unsigned long long ray_base, InterDump idump) {
     __shared__ f4 tiles[4][64 + 256];                           // per wave: 4x4x4 tile + 8x8x4 brick (device_volume_coop.hpp)
