@@ -209,7 +209,10 @@ def main():
                 "kernel": f"march_kernel<rk4,{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
                 "bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
                 "sensor_taps_per_ray": round(a_bar, 2),
-                "compulsory_bytes": int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources)}
+                "compulsory_bytes": int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources),
+                "note": "achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time; the kernel serves them from LDS "
+                        "(each texel block is fetched once per wave), so frac > 1 and `traffic` (measured HBM bytes per "
+                        "launch) is tiny: the launch is bound by the VALU and LDS pipes, see valu_f32 and DESIGN.md 4.1"}
 
     # secondary views of the same launch: with the block staged through LDS the march is
     # VALU/LDS-bound, so also price it against the f32 vector peak, and measure what a plain
