@@ -336,6 +336,12 @@ int photon_volume_gaussian(int nx, int ny, int nz, const double spacing[3], cons
                            double rho0, double amp, const double centre[3], double sigma,
                            int interpolation, photon_volume_t **out);
 
+/* The same Gaussian density field written as an NRRD file (type float, dimension 3, raw, little endian, sizes /
+ * spacings / space origin: what nrrd_functions.py:14-57 writes and loadNRRD reads), evaluated on the device. */
+int photon_density_gaussian_write_nrrd(const char *path, int nx, int ny, int nz, const double spacing[3],
+                                       const double origin[3], double rho0, double amp,
+                                       const double centre[3], double sigma);
+
 /* Library / build identification string (static storage). */
 const char *photon_version(void);
 

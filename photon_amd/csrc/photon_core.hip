@@ -716,6 +716,22 @@ int photon_volume_from_density(const float *rho, int nx, int ny, int nz, const d
 // Synthetic density field evaluated on the device: rho = rho0 + amp * exp(-|r - centre|^2 / (2 sigma^2)),
 // separable, so the host prepares three axis profiles (O(n) work, photon_det_exp) and a kernel fills the
 // n^3 grid in HBM -- no host array, no file, no upload (BASELINE C3 / C4's volume).
+// the three axis profiles of the separable Gaussian, on the device
+static int gaussian_profiles(int nx, int ny, int nz, const double spacing[3], const double origin[3],
+                             const double centre[3], double sigma, double *d_prof[3]) {
+    const int dims[3] = {nx, ny, nz};
+    for (int a = 0; a < 3; a++) {
+        std::vector<double> prof(dims[a]);
+        for (int i = 0; i < dims[a]; i++) {
+            const double x = origin[a] + spacing[a] * (double)i;
+            prof[i] = photon_det_exp(-((x - centre[a]) * (x - centre[a])) / (2 * (sigma * sigma)));
+        }
+        if (hipMalloc((void **)&d_prof[a], dims[a] * sizeof(double)) != hipSuccess ||
+            hipMemcpy(d_prof[a], prof.data(), dims[a] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return 3;
+    }
+    return 0;
+}
+
 int photon_volume_gaussian(int nx, int ny, int nz, const double spacing[3], const double origin[3], double rho0,
                            double amp, const double centre[3], double sigma, int interpolation,
                            photon_volume_t **out) {
@@ -723,19 +739,8 @@ int photon_volume_gaussian(int nx, int ny, int nz, const double spacing[3], cons
         fprintf(stderr, "photon: photon_volume_gaussian: bad arguments\n");
         return 1;
     }
-    const int dims[3] = {nx, ny, nz};
-    std::vector<double> prof[3];
     double *d_prof[3] = {nullptr, nullptr, nullptr};
-    int rc = 0;
-    for (int a = 0; a < 3 && !rc; a++) {
-        prof[a].resize(dims[a]);
-        for (int i = 0; i < dims[a]; i++) {
-            const double x = origin[a] + spacing[a] * (double)i;
-            prof[a][i] = photon_det_exp(-((x - centre[a]) * (x - centre[a])) / (2 * (sigma * sigma)));
-        }
-        if (hipMalloc((void **)&d_prof[a], dims[a] * sizeof(double)) != hipSuccess ||
-            hipMemcpy(d_prof[a], prof[a].data(), dims[a] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = 3;
-    }
+    int rc = gaussian_profiles(nx, ny, nz, spacing, origin, centre, sigma, d_prof);
     if (!rc) {
         DensitySource src;
         src.d_gx = d_prof[0]; src.d_gy = d_prof[1]; src.d_gz = d_prof[2];
@@ -746,6 +751,46 @@ int photon_volume_gaussian(int nx, int ny, int nz, const double spacing[3], cons
     }
     for (double *p : d_prof) if (p) (void)hipFree(p);
     return rc;
+}
+
+// The same field written as an NRRD file (what nrrd_functions.py:14-57 writes with pynrrd and loadNRRD reads
+// back: type float, dimension 3, raw, little endian, sizes / spacings / space origin): evaluated on the device,
+// streamed to disk.  For feeding synthetic volumes to code that wants a file -- photon itself included.
+int photon_density_gaussian_write_nrrd(const char *path, int nx, int ny, int nz, const double spacing[3],
+                                       const double origin[3], double rho0, double amp, const double centre[3],
+                                       double sigma) {
+    if (!path || !spacing || !origin || !centre || !(sigma > 0) || nx < 1 || ny < 1 || nz < 1) {
+        fprintf(stderr, "photon: photon_density_gaussian_write_nrrd: bad arguments\n");
+        return 1;
+    }
+    double *d_prof[3] = {nullptr, nullptr, nullptr};
+    float *d_rho = nullptr;
+    const size_t n = (size_t)nx * ny * nz;
+    std::vector<float> rho;
+    int rc = gaussian_profiles(nx, ny, nz, spacing, origin, centre, sigma, d_prof);
+    if (!rc && hipMalloc((void **)&d_rho, n * sizeof(float)) != hipSuccess) rc = 3;
+    if (!rc) {
+        hipLaunchKernelGGL(separable_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_prof[0], d_prof[1],
+                           d_prof[2], nx, ny, nz, rho0, amp, d_rho);
+        rho.resize(n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(rho.data(), d_rho, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = 4;
+    }
+    for (double *p : d_prof) if (p) (void)hipFree(p);
+    if (d_rho) (void)hipFree(d_rho);
+    if (rc) {
+        fprintf(stderr, "photon: photon_density_gaussian_write_nrrd: HIP error\n");
+        return rc;
+    }
+    std::ofstream f(path, std::ios::out | std::ios::binary);
+    if (!f) { fprintf(stderr, "photon: cannot write %s\n", path); return 2; }
+    char header[512];
+    snprintf(header, sizeof header,
+             "NRRD0005\n# written by photon_density_gaussian_write_nrrd\ntype: float\ndimension: 3\nspace: 3D-left-handed\n"
+             "sizes: %d %d %d\nendian: little\nencoding: raw\nspacings: %.17g %.17g %.17g\nspace origin: (%.17g,%.17g,%.17g)\n\n",
+             nx, ny, nz, spacing[0], spacing[1], spacing[2], origin[0], origin[1], origin[2]);
+    f.write(header, (std::streamsize)strlen(header));
+    f.write(reinterpret_cast<const char *>(rho.data()), (std::streamsize)(n * sizeof(float)));
+    return f ? 0 : 2;
 }
 
 static int volume_build(const DensitySource &src, int nx, int ny, int nz, const double spacing[3],

@@ -24,7 +24,7 @@ DECLARED_SYMBOLS = (
     "photon_trace_volume_rays", "photon_version",
     # section 3: scene generation on the device
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
-    "photon_scene_create_from_sources", "photon_volume_gaussian",
+    "photon_scene_create_from_sources", "photon_volume_gaussian", "photon_density_gaussian_write_nrrd",
 )
 
 
@@ -166,6 +166,20 @@ class PhotonLibrary:
                                                     _ptr(c), float(sigma), int(interpolation), ctypes.byref(h)),
                     "photon_volume_gaussian")
         return Volume(self, h)
+
+    def density_gaussian_write_nrrd(self, path: str, n, spacing, origin, rho0: float, amp: float, centre, sigma: float) -> str:
+        """The field of volume_gaussian as an NRRD file (evaluated on the device)."""
+        nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+        sp = np.ascontiguousarray(np.broadcast_to(np.asarray(spacing, np.float64), (3,)))
+        og = np.ascontiguousarray(origin, dtype=np.float64)
+        c = np.ascontiguousarray(centre, dtype=np.float64)
+        self.lib.photon_density_gaussian_write_nrrd.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+                                                                ctypes.c_double, ctypes.c_void_p, ctypes.c_double]
+        self._check(self.lib.photon_density_gaussian_write_nrrd(path.encode(), int(nx), int(ny), int(nz), _ptr(sp), _ptr(og),
+                                                                float(rho0), float(amp), _ptr(c), float(sigma)),
+                    "photon_density_gaussian_write_nrrd")
+        return path
 
     # ---- sources generated on the device ------------------------------------------------------
     def sources_bos(self, dot_xy, template_xy, z: float, radiance: float) -> "Sources":

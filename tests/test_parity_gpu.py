@@ -398,7 +398,7 @@ def test_render_with_other_integrators(photon, oracle, small_volume_file, algori
     assert np.array_equal(photon.render(call), g)
 
 
-def test_scene_generation_on_device(photon, oracle, monkeypatch):
+def test_scene_generation_on_device(photon, oracle, monkeypatch, tmp_path):
     """include/parallel_ray_tracing.h section 3: BOS and PIV sources and the synthetic
     Gaussian volume built in HBM are bit-identical to the CPU restatement (and, for BOS, to the numpy arrays the
     host path uploads), and a scene created from them renders the same image as one created from host arrays."""
@@ -438,6 +438,14 @@ def test_scene_generation_on_device(photon, oracle, monkeypatch):
         scene.free()
     assert imgs[0].any() and rel_l2(imgs[0], imgs[1]) <= IMAGE_TOL          # (volumes differ by the exp's last ulp)
     src.free(); vol.free(); vol_host.free()
+    # --- the same field as an NRRD file: read back by our loader (and by scenes.read_nrrd) it is the volume built in place
+    path = photon.density_gaussian_write_nrrd(str(tmp_path / "gauss40.nrrd"), 40, sp, org, 1.225, 0.2, centre, 8.0e3)
+    from_file, in_place = photon.volume_load_nrrd(path, 1), photon.volume_gaussian(40, sp, org, 1.225, 0.2, centre, 8.0e3, 1)
+    assert_bit_equal(from_file.download(), in_place.download(), "NRRD written from the device vs volume built in place")
+    rho_file, sp_file, org_file = scenes.read_nrrd(path)
+    assert rho_file.shape == (40, 40, 40) and np.allclose(sp_file, sp) and np.allclose(org_file, org)
+    np.testing.assert_allclose(rho_file, rho, rtol=3e-7)
+    from_file.free(); in_place.free()
     # --- PIV field: bit-identical to the CPU restatement, with and without a diameter distribution
     lo, hi = (-3.0e4, -3.0e4, -7.5e3), (3.0e4, 3.0e4, 7.5e3)
     cdf = np.cumsum(np.full(27, 1.0 / 27.0))
