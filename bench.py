@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """bench.py - Mrays/s of the ray-tracing hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config C3 of BASELINE.json): BOS render, 2e4 light-field sources x
-500 rays = 1e7 rays PER GPU through a 256^3 density-gradient volume, RK4 with the tricubic
-B-spline sampler, thick-lens camera, erf splat (D = 3 px) onto a 1024^2 sensor.  One "step" = one
-full render of the rank's sources with everything (sources, tables, volume, image) already
-resident in HBM: zero the private image, trace, and -- for N > 1 -- sum-reduce the image onto
-rank 0 (RCCL).  Weak scaling: every rank renders its own 1e7-ray shard of an N x 1e7-ray job.
+500 rays = 1e7 rays through a 256^3 density-gradient volume, RK4 with the tricubic B-spline sampler,
+thick-lens camera, erf splat (D = 3 px) onto a 1024^2 sensor.  One "step" = one full render with
+everything (sources, tables, volume, image) already resident in HBM: zero the private image, trace
+the rank's sources, and -- for N > 1 -- sum-reduce the image onto rank 0 (RCCL over xGMI).
+
+Multi-GPU (one process per GPU).  `--gpus N` without a launcher environment starts its own N ranks
+(torch.distributed.run as a child process; the parent never touches the GPU) and fails loudly when the
+node has fewer than N devices.
+  --scaling strong (default)  ONE 1e7-ray job, its sources split with sharding.shard_range: the literal
+                              BASELINE metric "1e7-ray 256^3 BOS render @1/2/4/8 GPU"
+  --scaling weak              every rank renders its own 1e7-ray scene (N x 1e7 rays per step)
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline      algorithmic bytes of the march kernel / its HIP-event duration vs the HBM peak
+  roofline      the march kernel against the pipe that bounds it (LDS reads), its
+                algorithmic bytes, f32 VALU fraction and the measured HBM traffic
   cpu_baseline  the CPU oracle (scalar C++ restatement, OpenMP) timed on a bounded sample
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -28,40 +39,27 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # HBM3E spec (6.29 TB/s measured float4 copy)
+LDS_PEAK_GBS = 150000.0          # aggregate ds_read_b64/b128 rate with every CU streaming (256 B/clk/CU x 256 CUs x 2.4 GHz)
+VALU_F32_PEAK_TFLOPS = 157.3     # vector f32 (256 CUs x 4 SIMD x 32 lanes/clk FMA x 2.4 GHz x 2)
 TEXELS_PER_SAMPLE = {1: 8, 2: 64}
 
 
-VALU_F32_PEAK_TFLOPS = 157.3     # MI355X vector f32 (256 CUs x 4 SIMD x 32 lanes/clk FMA x 2.4 GHz x 2)
-
-
-def measure_copy_bandwidth(nbytes: int = 1 << 30, reps: int = 5) -> float:
-    """Device-to-device copy rate (read + write bytes) in GB/s: the HBM rate a trivial kernel reaches here."""
-    import torch
-    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    b = torch.empty_like(a)
-    b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) * 1e-9
-
-
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--interp", choices=["cubic", "linear"], default="cubic")
     ap.add_argument("--volume", type=int, default=256, help="grid points per axis of the density volume")
-    ap.add_argument("--dots", type=int, default=200, help="BOS dots per GPU (x100 sources x500 rays)")
+    ap.add_argument("--dots", type=int, default=200, help="BOS dots of the job (strong) / per GPU (weak); x100 sources x500 rays")
     ap.add_argument("--rays-per-source", type=int, default=500)
     ap.add_argument("--cpu-sample-rays", type=int, default=500000, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--check", action="store_true", help="also verify a slice of the image against the oracle")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def cpu_budget() -> int:
@@ -87,6 +85,53 @@ def cpu_budget() -> int:
     return int(env) if env else n
 
 
+# --------------------------------------------------------------------------------------------------
+# self-launch: `bench.py --gpus N` outside a launcher starts N ranks as a CHILD process
+# --------------------------------------------------------------------------------------------------
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """Parent of a multi-GPU run.  Makes no HIP / torch.cuda call that initialises the GPU
+    (device_count() does not), so starting children is safe; never re-execs."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to run "
+              f"{args.gpus} ranks on fewer devices", file=sys.stderr, flush=True)
+        return 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# --------------------------------------------------------------------------------------------------
+# side measurements
+# --------------------------------------------------------------------------------------------------
+
+
+def measure_copy_bandwidth(nbytes: int = 1 << 30, reps: int = 5) -> float:
+    """Device-to-device copy rate (read + write bytes) in GB/s: the HBM rate a trivial kernel reaches here."""
+    import torch
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) * 1e-9
+
+
 def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source):
     """Time the oracle's ray loop (volume prebuilt, like the GPU side) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -106,154 +151,45 @@ def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source
                       f"ray loop only (volume prebuilt), {dt:.1f} s"}
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    from photon_amd import scenes
-    from photon_amd.library import PhotonLibrary
-    from photon_amd.sharding import reduce_image
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
-    if world > 1 or under_launcher:         # one process per GPU over RCCL (also exercised at world_size 1)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    interp = 2 if args.interp == "cubic" else 1
-
-    # ---- synthetic inputs (host) -> resident in HBM ------------------------------------------
-    workdir = os.environ.get("PHOTON_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "photon_bench")
-    os.makedirs(workdir, exist_ok=True)
-    vol_path = os.path.join(workdir, f"bos_{args.volume}.nrrd")
-    if rank == 0 and not os.path.exists(vol_path):
-        rho, sp, org = scenes.bos_volume(args.volume)
-        scenes.write_nrrd(vol_path + ".tmp", rho, sp, org)
-        os.replace(vol_path + ".tmp", vol_path)
-    if dist.is_initialized():
-        dist.barrier()
-
-    def make_call(seed=1 + rank, n_dots=args.dots, n_sources=None):
-        c = scenes.bos_scene(n_dots=n_dots, points_per_dot=100, rays_per_source=args.rays_per_source,
-                             density_grad_filename=vol_path, seed=seed)
-        if n_sources is not None:       # leading slice of the same source list
-            for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
-                setattr(c, f, getattr(c, f)[:n_sources])
-        return c
-
-    lib = PhotonLibrary()
-    call = make_call()
-    scene = lib.scene_create(call)
+def measure_hbm_traffic(args, kernel_tag: str):
+    """HBM bytes per launch of the march kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE each in its own run, no tracing alongside) over a short child run of this same bench, corrected
+    as MI355X_MICROARCH.md section HBM prescribes for gfx950 (FETCH_SIZE x2 for wide coalesced reads; both in
+    KiB).  Returns (bytes or None, detail dict).  The children are ordinary child processes of this one."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"source": "unavailable: rocprofv3 not found"}
+    means = {}
     t0 = time.perf_counter()
-    volume = lib.volume_load_nrrd(vol_path, interp)
-    torch.cuda.synchronize()
-    volume_build_s = time.perf_counter() - t0
-    H, W = call.image_shape
-    image = torch.zeros(H * W, dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(want_stats):
-        image.zero_()
-        st = scene.trace(image.data_ptr(), volume, 2, 0, call.num_sources, stream=stream, want_stats=want_stats)
-        reduce_image(image, 0)
-        return st
-
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    march_ms, iters, samples, taps, on_sensor = 0.0, 0, 0, 0, 0
-    for _ in range(args.steps):
-        st = step(True)               # HIP events bracket the march kernel on the launch stream
-        march_ms += st.march_ms
-        iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    rays_per_gpu = call.num_rays
-    total_rays = rays_per_gpu * world
-    value = total_rays * args.steps / elapsed * 1e-6
-
-    # ---- roofline of the dominant kernel (march_kernel<rk4, interp>) ---------------------------
-    s_bar = iters / rays_per_gpu
-    a_bar = taps / rays_per_gpu
-    bytes_per_ray = s_bar * 3 * TEXELS_PER_SAMPLE[interp] * 16 + a_bar * 8 + 40      # SURVEY.md 8d
-    march_ms_avg = march_ms / args.steps
-    achieved = rays_per_gpu * bytes_per_ray / (march_ms_avg * 1e-3) * 1e-9 if march_ms_avg > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")      # written from rocprofv3 --pmc runs
-    if os.path.exists(pmc):
-        try:
-            with open(pmc) as f:
-                traffic = json.load(f).get(f"march_{args.interp}_{args.volume}", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": f"march_kernel<rk4,{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
-                "bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
-                "sensor_taps_per_ray": round(a_bar, 2),
-                "compulsory_bytes": int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources),
-                "note": "achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time; the kernel serves them from LDS "
-                        "(each texel block is fetched once per wave), so frac > 1 and `traffic` (measured HBM bytes per "
-                        "launch) is tiny: the launch is bound by the VALU and LDS pipes, see valu_f32 and DESIGN.md 4.1"}
-
-    # secondary views of the same launch: with the block staged through LDS the march is
-    # VALU/LDS-bound, so also price it against the f32 vector peak, and measure what a plain
-    # device-to-device copy reaches on this box ("achievable" HBM peak)
-    flops_per_sample = {"linear": 100.0, "cubic": 570.0}[args.interp]            # SURVEY.md 8d
-    flops = samples * flops_per_sample + iters * 120.0
-    tflops = flops / (march_ms_avg * 1e-3) * 1e-12 if march_ms_avg > 0 else 0.0
-    roofline["valu_f32"] = {"achieved": round(tflops, 2), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "flops_per_sample": flops_per_sample}
-    if rank == 0:
-        roofline["hbm_copy_measured_gbs"] = round(measure_copy_bandwidth(), 1)
-
-    out = None
-    if rank == 0:
-        cpu = None
-        if args.cpu_sample_rays > 0 and world == 1:      # the CPU baseline is reported at N=1 only
-            cpu = cpu_baseline(lambda n_sources: make_call(seed=1, n_sources=n_sources), vol_path, interp,
-                               args.cpu_sample_rays, args.rays_per_source)
-        out = {
-            "metric": "Mrays/sec, 1e7-ray 256^3 BOS render (HBM GB/s %peak under roofline)",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: BOS, {rays_per_gpu} rays/GPU ({call.num_sources} sources x "
-                                   f"{args.rays_per_source}), {args.volume}^3 volume, RK4, {args.interp} sampler, "
-                                   f"erf splat D=3, 1024^2 sensor",
-                       "rays_total": total_rays, "parallelism": f"sources sharded x{world}, RCCL sum-reduce of the image"},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "volume_build_s": round(volume_build_s, 3), "rays_on_sensor": int(on_sensor),
-        }
-        if world == 1:
-            out["abi_call"] = time_abi_call(lib, call, interp)
-        if args.check:
-            out["check"] = check_against_oracle(lib, make_call, vol_path, interp)
-        print(json.dumps(out), flush=True)
-    scene.free()
-    volume.free()
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
-    return out
+    with tempfile.TemporaryDirectory(prefix="photon_pmc_", dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-sample-rays", "0", "--no-traffic",
+                   "--interp", args.interp, "--volume", str(args.volume), "--dots", str(args.dots),
+                   "--rays-per-source", str(args.rays_per_source)]
+            env = dict(os.environ, TMPDIR="/tmp", PHOTON_BENCH_CHILD="1")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+                env.pop(k, None)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, {"source": f"unavailable: rocprofv3 --pmc {counter} pass timed out"}
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                tail = r.stdout.decode("utf-8", "replace")[-300:].replace("\n", " | ")
+                return None, {"source": f"unavailable: rocprofv3 --pmc {counter} pass gave no rows (rc {r.returncode}): {tail}"}
+            means[counter] = sum(vals) / len(vals)
+    traffic = int(means["FETCH_SIZE"] * 1024 * 2 + means["WRITE_SIZE"] * 1024)
+    return traffic, {"source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per launch",
+                     "FETCH_SIZE_KiB": round(means["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(means["WRITE_SIZE"], 1),
+                     "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as counted",
+                     "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def time_abi_call(lib, call, interp):
@@ -279,6 +215,185 @@ def check_against_oracle(lib, make_call, vol_path, interp):
     g = lib.render(call).astype(np.float64)
     c, _ = o.render(call, interpolation=interp)
     return {"rel_l2": float(np.linalg.norm(g - c) / np.linalg.norm(c)), "sources": 40}
+
+
+# --------------------------------------------------------------------------------------------------
+# one rank
+# --------------------------------------------------------------------------------------------------
+
+
+def main():
+    args = parse_args()
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+
+    from photon_amd import scenes
+    from photon_amd.library import PhotonLibrary
+    from photon_amd.sharding import reduce_image, shard_range
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(local_rank)
+    if under_launcher:                      # one process per GPU over RCCL (also exercised at world_size 1)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    interp = 2 if args.interp == "cubic" else 1
+
+    # ---- synthetic inputs (host) -> resident in HBM ------------------------------------------
+    workdir = os.environ.get("PHOTON_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "photon_bench")
+    os.makedirs(workdir, exist_ok=True)
+    vol_path = os.path.join(workdir, f"bos_{args.volume}.nrrd")
+    if rank == 0 and not os.path.exists(vol_path):
+        rho, sp, org = scenes.bos_volume(args.volume)
+        scenes.write_nrrd(vol_path + f".tmp{os.getpid()}", rho, sp, org)
+        os.replace(vol_path + f".tmp{os.getpid()}", vol_path)
+    if dist.is_initialized():
+        dist.barrier()
+
+    def make_call(seed=1, n_dots=args.dots, n_sources=None):
+        c = scenes.bos_scene(n_dots=n_dots, points_per_dot=100, rays_per_source=args.rays_per_source,
+                             density_grad_filename=vol_path, seed=seed)
+        if n_sources is not None:       # leading slice of the same source list
+            for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+                setattr(c, f, getattr(c, f)[:n_sources])
+        return c
+
+    lib = PhotonLibrary()
+    lib.set_device(local_rank)
+    strong = args.scaling == "strong"
+    # strong: every rank holds the ONE job's scene and traces its shard_range of the sources;
+    # weak:   every rank has its own scene (different dots) and traces all of it
+    call = make_call(seed=1 if strong else 1 + rank)
+    src_begin, src_end = shard_range(call.num_sources, rank, world) if strong else (0, call.num_sources)
+    scene = lib.scene_create(call)
+    t0 = time.perf_counter()
+    volume = lib.volume_load_nrrd(vol_path, interp)
+    torch.cuda.synchronize()
+    volume_build_s = time.perf_counter() - t0
+    H, W = call.image_shape
+    image = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(want_stats):
+        image.zero_()
+        st = scene.trace(image.data_ptr(), volume, 2, src_begin, src_end, stream=stream, want_stats=want_stats)
+        reduce_image(image, 0)
+        return st
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    march_ms, iters, samples, taps, on_sensor = 0.0, 0, 0, 0, 0
+    for _ in range(args.steps):
+        st = step(True)               # HIP events bracket the march kernel on the launch stream
+        march_ms += st.march_ms
+        iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rays_rank = (src_end - src_begin) * args.rays_per_source
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([rays_rank, on_sensor], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_rays, on_sensor_total = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        total_rays, on_sensor_total = rays_rank, int(on_sensor)
+    value = total_rays * args.steps / elapsed * 1e-6
+
+    # ---- roofline of the dominant kernel (march_kernel<rk4, interp>), this rank's launch --------
+    s_bar = iters / max(rays_rank, 1)
+    a_bar = taps / max(rays_rank, 1)
+    bytes_per_ray = s_bar * 3 * TEXELS_PER_SAMPLE[interp] * 16 + a_bar * 8 + 40      # SURVEY.md 8d
+    march_ms_avg = march_ms / args.steps
+    achieved = rays_rank * bytes_per_ray / (march_ms_avg * 1e-3) * 1e-9 if march_ms_avg > 0 else 0.0
+    flops_per_sample = {"linear": 100.0, "cubic": 570.0}[args.interp]                # SURVEY.md 8d
+    flops = samples * flops_per_sample + iters * 120.0
+    tflops = flops / (march_ms_avg * 1e-3) * 1e-12 if march_ms_avg > 0 else 0.0
+    compulsory = int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources)
+    # The march serves its texels from LDS: a wave fetches each block once and every lane reads it back with
+    # broadcast ds_read_b128, so the ALGORITHMIC bytes of SURVEY 8d (S x 3 x T x 16 per ray) are exactly the bytes
+    # the kernel pulls through the LDS read pipe; they never were HBM bytes.  The bound that prices them is the LDS
+    # aggregate read rate; the f32 VALU (the separable FMA chain) is the co-limiter.  For the trilinear kernel (8
+    # texels per sample) neither pipe is near its peak: it is instruction-issue bound.
+    roofline = {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / LDS_PEAK_GBS, 4), "traffic": None,
+                "kernel": f"march_kernel<rk4,{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
+                "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
+                "sensor_taps_per_ray": round(a_bar, 2), "rays_per_launch": rays_rank,
+                "valu_f32": {"achieved": round(tflops, 2), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "flops_per_sample": flops_per_sample},
+                "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "compulsory_bytes": compulsory, "traffic": None,
+                        "traffic_gbs": None, "frac": None},
+                "note": "bound = the pipe the kernel actually moves SURVEY 8d's algorithmic bytes through: LDS broadcast "
+                        "reads (guide: ~150 TB/s aggregate), co-limited by the f32 VALU chain (valu_f32); HBM only sees the "
+                        "ray state and one pass over the touched texels (hbm.traffic, measured by rocprofv3 --pmc in this run)"}
+
+    out = None
+    if rank == 0:
+        roofline["hbm"]["copy_measured_gbs"] = round(measure_copy_bandwidth(), 1)
+        cpu = None
+        if args.cpu_sample_rays > 0 and world == 1:      # the CPU baseline is reported at N=1 only
+            cpu = cpu_baseline(lambda n_sources: make_call(seed=1, n_sources=n_sources), vol_path, interp,
+                               args.cpu_sample_rays, args.rays_per_source)
+        if world == 1 and not args.no_traffic and not os.environ.get("PHOTON_BENCH_CHILD"):
+            traffic, detail = measure_hbm_traffic(args, "march_kernel")
+            roofline["traffic"] = traffic
+            roofline["hbm"].update(detail)
+            roofline["hbm"]["traffic"] = traffic
+            if traffic and march_ms_avg > 0:
+                gbs = traffic / (march_ms_avg * 1e-3) * 1e-9
+                roofline["hbm"]["traffic_gbs"] = round(gbs, 1)
+                roofline["hbm"]["frac"] = round(gbs / HBM_PEAK_GBS, 4)
+        desc = (f"C3: BOS, {total_rays} rays ({call.num_sources} sources x {args.rays_per_source}"
+                f"{' per GPU' if not strong and world > 1 else ''}), {args.volume}^3 volume, RK4, {args.interp} sampler, "
+                f"erf splat D=3, 1024^2 sensor")
+        out = {
+            "metric": "Mrays/sec, 1e7-ray 256^3 BOS render", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "rays_total": total_rays,
+                       "parallelism": (f"{world} rank(s), one per GPU; sources of ONE job split by shard_range, "
+                                       if strong else f"{world} rank(s), one per GPU, one scene each; ")
+                                      + "private images, one RCCL sum-reduce onto rank 0 per step",
+                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "volume_build_s": round(volume_build_s, 3), "rays_on_sensor": on_sensor_total,
+        }
+        if world == 1 and not os.environ.get("PHOTON_BENCH_CHILD"):
+            out["abi_call"] = time_abi_call(lib, call, interp)
+        if args.check:
+            out["check"] = check_against_oracle(lib, make_call, vol_path, interp)
+        print(json.dumps(out), flush=True)
+    scene.free()
+    volume.free()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

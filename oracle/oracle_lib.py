@@ -75,7 +75,7 @@ class Oracle:
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
 
     # ---- full pipeline --------------------------------------------------------------------
-    def render(self, call: RayTracingCall, image=None, interpolation: int = 1, tex_frac_bits: int = 0):
+    def render(self, call: RayTracingCall, image=None, interpolation: int = 1, tex_frac_bits: int = 8):
         if image is None:
             image = call.new_image()
         st = oracle_stats_t()
@@ -119,7 +119,7 @@ class Oracle:
         return y
 
     # ---- volume ---------------------------------------------------------------------------
-    def volume_from_density(self, rho, spacing, origin, interpolation=1, tex_frac_bits=0):
+    def volume_from_density(self, rho, spacing, origin, interpolation=1, tex_frac_bits=8):
         rho = np.ascontiguousarray(rho, dtype=np.float32)
         nz, ny, nx = rho.shape
         sp = np.ascontiguousarray(spacing, dtype=np.float64)
@@ -127,7 +127,7 @@ class Oracle:
         h = self.lib.oracle_volume_from_density(_p(rho), nx, ny, nz, _p(sp), _p(og), interpolation, tex_frac_bits)
         return OracleVolume(self, h)
 
-    def volume_gaussian(self, n, spacing, origin, rho0, amp, centre, sigma, interpolation=1, tex_frac_bits=0):
+    def volume_gaussian(self, n, spacing, origin, rho0, amp, centre, sigma, interpolation=1, tex_frac_bits=8):
         nx, ny, nz = (n, n, n) if np.isscalar(n) else n
         sp = np.ascontiguousarray(np.broadcast_to(np.asarray(spacing, np.float64), (3,)))
         og = np.ascontiguousarray(origin, dtype=np.float64)
@@ -164,7 +164,7 @@ class Oracle:
                                     _p(out["radiance"]), _p(out["diameter_index"]))
         return out
 
-    def volume_load_nrrd(self, path, interpolation=1, tex_frac_bits=0):
+    def volume_load_nrrd(self, path, interpolation=1, tex_frac_bits=8):
         h = self.lib.oracle_volume_load_nrrd(path.encode(), interpolation, tex_frac_bits)
         assert h, f"oracle could not read {path}"
         return OracleVolume(self, h)

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libparallel_ray_tracing.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 
-SOURCES = [os.path.join(CSRC, "photon_core.hip")]
+SOURCES = [os.path.join(CSRC, "photon_core.hip"), os.path.join(CSRC, "photon_sort.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp", "device_volume_coop.hpp", "device_volume_extra.hpp", "device_optics.hpp")] + [
     os.path.join(ROOT, "include", "parallel_ray_tracing.h"),
     os.path.join(ROOT, "include", "photon_det_math.h"),
@@ -32,10 +32,15 @@ HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp"
 # -fno-slp-vectorize: v_pk_*_f32 issue at half the rate of the unpacked forms on gfx950 (measured:
 #   tools/ubench/fma_rate.hip), so SLP packing only adds operand shuffles.
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-munsafe-fp-atomics", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function",
 ]
+# RUNPATH: the unversioned ROCm prefix, so the library finds libamdhip64 on a box whose ROCm point release differs
+# from the build box's (hipcc's own default is the versioned /opt/rocm-X.Y.Z/lib of the machine it ran on).
+LINK_FLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-Wl,--enable-new-dtags", "-Wl,-rpath,/opt/rocm/lib",
+              "-L/opt/rocm/lib", "-lamdhip64"]
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
 
 
 def hipcc_path() -> str:
@@ -52,14 +57,38 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + [os.path.abspath(__file__)])
 
 
-def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB_PATH] + SOURCES
+def _compile(src: str, extra_flags, verbose: bool, out_dir: str) -> str:
+    obj = os.path.join(out_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC, stdout=sys.stderr)
-    return LIB_PATH
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out_path: str = None) -> str:
+    """Compile every translation unit (in parallel) and link the shared library.  Concurrent callers (ranks of one
+    node, pytest workers) serialise on a lock file; whoever comes second finds the library fresh."""
+    import fcntl
+    from concurrent.futures import ThreadPoolExecutor
+    target = out_path or LIB_PATH
+    if out_path is None and not force and not needs_build():
+        return LIB_PATH
+    obj_dir = OBJ_DIR if out_path is None else os.path.join(OBJ_DIR, os.path.basename(target) + ".d")
+    os.makedirs(obj_dir, exist_ok=True)
+    with open(os.path.join(obj_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if out_path is None and not force and not needs_build():
+            return LIB_PATH
+        with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+            objs = list(pool.map(lambda src: _compile(src, extra_flags, verbose, obj_dir), SOURCES))
+        tmp = target + f".tmp{os.getpid()}"
+        cmd = [hipcc_path()] + LINK_FLAGS + ["-o", tmp] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr, flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC, stdout=sys.stderr)
+        os.replace(tmp, target)
+    return target
 
 
 if __name__ == "__main__":

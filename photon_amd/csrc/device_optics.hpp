@@ -63,7 +63,10 @@ struct SceneDev {
     // point of the lens (every source uses the same lens-sample table, .cu:2006), which is what stays
     // coherent when the cone is as wide as the aperture (PIV through a volume).
     int ray_order;
-    const int *src_perm;                // spatial order of the sources (lens-major only); nullptr = identity
+    const int *src_perm;                // spatial order of THIS launch's sources (lens-major only); nullptr = identity
+    // index of this scene's source 0 in the caller's source list (PHOTON_DEVICES uploads each device only its
+    // shard): keeps the noise generator's per-ray key independent of the sharding
+    long long source_base;
     // > 0: rays whose UNDEFLECTED path meets element 0's front surface more than pitch/2 + doom_margin from the
     // axis are not marched (they are killed there whatever the volume does, .cu:560-566 / :447); 0 = off
     float doom_margin;
@@ -79,8 +82,8 @@ __device__ __forceinline__ void slot_to_ray(const SceneDev &sc, long long src_be
     } else {
         const unsigned n_src = n_rays / rps;
         local_ray = (int)(r / n_src);
-        const long long pos = src_begin + r % n_src;
-        source = sc.src_perm ? sc.src_perm[pos] : (int)pos;
+        const unsigned k = r % n_src;                                   // src_perm covers exactly this launch's range
+        source = sc.src_perm ? sc.src_perm[k] : (int)(src_begin + k);
     }
 }
 

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <map>
 #include <mutex>
@@ -63,6 +64,31 @@ static bool verbose() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("PHOTON_VERBOSE"); v = (e && atoi(e) > 0) ? 1 : 0; }
     return v == 1;
+}
+
+// a device allocation that is released on every return path
+template <typename T>
+struct DeviceBuffer {
+    T *p = nullptr;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+// No C++ exception may cross the C boundary (a ctypes caller would be terminated): every extern "C" body that
+// allocates host memory runs inside this guard.
+template <typename F>
+static int guarded(const char *what, F &&body) {
+    try {
+        return body();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "photon: %s failed: %s\n", what, e.what());
+    } catch (...) {
+        fprintf(stderr, "photon: %s failed: unknown exception\n", what);
+    }
+    return 100;
 }
 
 // =============================================================================================
@@ -469,7 +495,7 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
         }
         const bool dumping = dump.final_pos != nullptr && r < (unsigned)dump.num_save;
         // the ray's identity for the noise generator: independent of the launch order
-        const unsigned long long ray_id = (unsigned long long)source * (unsigned)sc.rays_per_source + (unsigned)local_ray;
+        const unsigned long long ray_id = (unsigned long long)(sc.source_base + source) * (unsigned)sc.rays_per_source + (unsigned)local_ray;
         f3 fin = nan3();
         bool have_fin = false;
         if (alive) {
@@ -573,7 +599,9 @@ struct photon_scene {
     int ray_order_mode = 2;             // 0 source-major, 1 lens-major, 2 auto (photon_scene_set_ray_order)
     bool skip_doomed = true;            // photon_scene_set_skip_doomed
     float lens_z = 0.f;                 // element 0's centre, for the auto rule
-    int *d_perm = nullptr;              // spatial (Morton) order of the sources, built on first lens-major launch
+    int *d_perm = nullptr;              // spatial (Morton) order of the sources of the last lens-major launch range
+    size_t perm_capacity = 0;
+    long long perm_begin = -1, perm_end = -1;
 };
 
 template <typename T>
@@ -655,7 +683,15 @@ static bool parse_nrrd(const char *path, std::vector<float> &rho, int dims[3], d
     if (type != "float") { why = "type must be float (single precision)"; return false; }
     if (encoding != "raw" || endian != "little") { why = "only raw little-endian encoding is supported"; return false; }
     if (dims[0] < 3 || dims[1] < 3 || dims[2] < 3) { why = "each axis needs at least 3 samples"; return false; }
-    rho.resize((size_t)dims[0] * dims[1] * dims[2]);
+    // a corrupt header must not drive the allocation: the payload has to be in the file
+    if (dims[0] > 65536 || dims[1] > 65536 || dims[2] > 65536) { why = "sizes beyond 65536 per axis"; return false; }
+    const unsigned long long count = (unsigned long long)dims[0] * dims[1] * dims[2];
+    const std::streamoff here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streamoff total = f.tellg();
+    f.seekg(here, std::ios::beg);
+    if (here < 0 || total < here || (unsigned long long)(total - here) < count * sizeof(float)) { why = "payload shorter than sizes"; return false; }
+    rho.resize((size_t)count);
     f.read(reinterpret_cast<char *>(rho.data()), (std::streamsize)(rho.size() * sizeof(float)));
     if ((size_t)f.gcount() != rho.size() * sizeof(float)) { why = "payload shorter than sizes"; return false; }
     return true;
@@ -710,7 +746,7 @@ int photon_volume_from_density(const float *rho, int nx, int ny, int nz, const d
     }
     DensitySource src;
     src.host_rho = rho;
-    return volume_build(src, nx, ny, nz, spacing, origin, interpolation, out);
+    return guarded("photon_volume_from_density", [&]() -> int { return volume_build(src, nx, ny, nz, spacing, origin, interpolation, out); });
 }
 
 // Synthetic density field evaluated on the device: rho = rho0 + amp * exp(-|r - centre|^2 / (2 sigma^2)),
@@ -740,12 +776,12 @@ int photon_volume_gaussian(int nx, int ny, int nz, const double spacing[3], cons
         return 1;
     }
     double *d_prof[3] = {nullptr, nullptr, nullptr};
-    int rc = gaussian_profiles(nx, ny, nz, spacing, origin, centre, sigma, d_prof);
+    int rc = guarded("photon_volume_gaussian", [&]() -> int { return gaussian_profiles(nx, ny, nz, spacing, origin, centre, sigma, d_prof); });
     if (!rc) {
         DensitySource src;
         src.d_gx = d_prof[0]; src.d_gy = d_prof[1]; src.d_gz = d_prof[2];
         src.rho0 = rho0; src.amp = amp;
-        rc = volume_build(src, nx, ny, nz, spacing, origin, interpolation, out);
+        rc = guarded("photon_volume_gaussian", [&]() -> int { return volume_build(src, nx, ny, nz, spacing, origin, interpolation, out); });
     } else {
         fprintf(stderr, "photon: photon_volume_gaussian: device allocation failed\n");
     }
@@ -767,12 +803,14 @@ int photon_density_gaussian_write_nrrd(const char *path, int nx, int ny, int nz,
     float *d_rho = nullptr;
     const size_t n = (size_t)nx * ny * nz;
     std::vector<float> rho;
-    int rc = gaussian_profiles(nx, ny, nz, spacing, origin, centre, sigma, d_prof);
+    int rc = guarded("photon_density_gaussian_write_nrrd", [&]() -> int {
+        rho.resize(n);
+        return gaussian_profiles(nx, ny, nz, spacing, origin, centre, sigma, d_prof);
+    });
     if (!rc && hipMalloc((void **)&d_rho, n * sizeof(float)) != hipSuccess) rc = 3;
     if (!rc) {
         hipLaunchKernelGGL(separable_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_prof[0], d_prof[1],
                            d_prof[2], nx, ny, nz, rho0, amp, d_rho);
-        rho.resize(n);
         if (hipGetLastError() != hipSuccess || hipMemcpy(rho.data(), d_rho, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = 4;
     }
     for (double *p : d_prof) if (p) (void)hipFree(p);
@@ -860,7 +898,7 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
     d.step_size = step;
     d.data_min = data_min;
     d.interpolation = interpolation;
-    d.weight_scale = 0.f;
+    d.weight_scale = 256.f;             // trilinear weights as the reference's texture unit holds them (photon_volume_set_weight_bits)
     d.texels = v->d_texels;
     d.coeffs = v->d_coeffs;
     photon_volume_info_t &info = v->info;
@@ -874,6 +912,8 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
 }
 
 int photon_volume_load_nrrd(const char *path, int interpolation, photon_volume_t **out) {
+  return guarded("photon_volume_load_nrrd", [&]() -> int {
+    if (!path || !out) { fprintf(stderr, "photon: photon_volume_load_nrrd: null argument\n"); return 1; }
     std::vector<float> rho;
     int dims[3];
     double spacing[3], origin[3];
@@ -886,6 +926,7 @@ int photon_volume_load_nrrd(const char *path, int interpolation, photon_volume_t
         printf("photon: NRRD %s  sizes %d %d %d  spacings %g %g %g  origin (%g,%g,%g)\n", path, dims[0], dims[1], dims[2],
                spacing[0], spacing[1], spacing[2], origin[0], origin[1], origin[2]);
     return photon_volume_from_density(rho.data(), dims[0], dims[1], dims[2], spacing, origin, interpolation, out);
+  });
 }
 
 int photon_volume_set_weight_bits(photon_volume_t *vol, int bits) {
@@ -911,14 +952,13 @@ int photon_volume_download(const photon_volume_t *vol, int coefficients, float *
 int photon_volume_sample(const photon_volume_t *vol, int n, const float *coords, float *out) {
     if (!vol || n < 0) return 1;
     if (n == 0) return 0;
-    float *d_c = nullptr, *d_o = nullptr;
-    PH_CHECK(hipMalloc((void **)&d_c, (size_t)n * 3 * sizeof(float)));
-    PH_CHECK(hipMalloc((void **)&d_o, (size_t)n * 4 * sizeof(float)));
-    PH_CHECK(hipMemcpy(d_c, coords, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(sample_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, vol->dev, n, d_c, d_o);
+    DeviceBuffer<float> d_c, d_o;                       // freed on every return path
+    PH_CHECK(d_c.alloc((size_t)n * 3));
+    PH_CHECK(d_o.alloc((size_t)n * 4));
+    PH_CHECK(hipMemcpy(d_c.p, coords, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sample_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, vol->dev, n, d_c.p, d_o.p);
     PH_CHECK(hipGetLastError());
-    PH_CHECK(hipMemcpy(out, d_o, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
-    (void)hipFree(d_c); (void)hipFree(d_o);
+    PH_CHECK(hipMemcpy(out, d_o.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -929,29 +969,28 @@ int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorit
         return 1;
     }
     if (n == 0) return 0;
-    float *d_p = nullptr, *d_d = nullptr;
-    int *d_s = nullptr;
+    DeviceBuffer<float> d_p, d_d;                       // freed on every return path
+    DeviceBuffer<int> d_s;
     const size_t b3 = (size_t)n * 3 * sizeof(float);
-    PH_CHECK(hipMalloc((void **)&d_p, b3));
-    PH_CHECK(hipMalloc((void **)&d_d, b3));
-    PH_CHECK(hipMalloc((void **)&d_s, (size_t)n * sizeof(int)));
-    PH_CHECK(hipMemcpy(d_p, pos, b3, hipMemcpyHostToDevice));
-    PH_CHECK(hipMemcpy(d_d, dir, b3, hipMemcpyHostToDevice));
+    PH_CHECK(d_p.alloc((size_t)n * 3));
+    PH_CHECK(d_d.alloc((size_t)n * 3));
+    PH_CHECK(d_s.alloc((size_t)n));
+    PH_CHECK(hipMemcpy(d_p.p, pos, b3, hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(d_d.p, dir, b3, hipMemcpyHostToDevice));
     const dim3 grid((n + 255) / 256), block(256);
     const int interp = vol->dev.interpolation;
     const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
-    if (ray_tracing_algorithm == 3) hipLaunchKernelGGL((march_rays_extra_kernel<3>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
-    else if (ray_tracing_algorithm == 4) hipLaunchKernelGGL((march_rays_extra_kernel<4>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
-    else if (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) hipLaunchKernelGGL((march_rays_extra_kernel<0>), grid, block, 0, 0, vol->dev, n, d_p, d_d, d_s);
-    else if (ray_tracing_algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_rays_kernel<1, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
-    else if (ray_tracing_algorithm == 1) hipLaunchKernelGGL((march_rays_kernel<1, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
-    else if (interp == 1) hipLaunchKernelGGL((march_rays_kernel<2, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
-    else hipLaunchKernelGGL((march_rays_kernel<2, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p, d_d, d_s);
+    if (ray_tracing_algorithm == 3) hipLaunchKernelGGL((march_rays_extra_kernel<3>), grid, block, 0, 0, vol->dev, n, d_p.p, d_d.p, d_s.p);
+    else if (ray_tracing_algorithm == 4) hipLaunchKernelGGL((march_rays_extra_kernel<4>), grid, block, 0, 0, vol->dev, n, d_p.p, d_d.p, d_s.p);
+    else if (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2) hipLaunchKernelGGL((march_rays_extra_kernel<0>), grid, block, 0, 0, vol->dev, n, d_p.p, d_d.p, d_s.p);
+    else if (ray_tracing_algorithm == 1 && interp == 1) hipLaunchKernelGGL((march_rays_kernel<1, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p.p, d_d.p, d_s.p);
+    else if (ray_tracing_algorithm == 1) hipLaunchKernelGGL((march_rays_kernel<1, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p.p, d_d.p, d_s.p);
+    else if (interp == 1) hipLaunchKernelGGL((march_rays_kernel<2, 1>), grid, block, 0, 0, vol->dev, tex, n, d_p.p, d_d.p, d_s.p);
+    else hipLaunchKernelGGL((march_rays_kernel<2, 2>), grid, block, 0, 0, vol->dev, tex, n, d_p.p, d_d.p, d_s.p);
     PH_CHECK(hipGetLastError());
-    PH_CHECK(hipMemcpy(pos, d_p, b3, hipMemcpyDeviceToHost));
-    PH_CHECK(hipMemcpy(dir, d_d, b3, hipMemcpyDeviceToHost));
-    if (steps) PH_CHECK(hipMemcpy(steps, d_s, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(d_p); (void)hipFree(d_d); (void)hipFree(d_s);
+    PH_CHECK(hipMemcpy(pos, d_p.p, b3, hipMemcpyDeviceToHost));
+    PH_CHECK(hipMemcpy(dir, d_d.p, b3, hipMemcpyDeviceToHost));
+    if (steps) PH_CHECK(hipMemcpy(steps, d_s.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1089,9 +1128,11 @@ int photon_scene_create(float lens_pitch, float image_distance, const scattering
                         int num_elements, const double (*element_center)[3], const element_data_t *edp,
                         const double (*element_plane_parameters)[4], const int *element_system_index,
                         const camera_design_t *cam, float ray_cone_pitch_ratio, photon_scene_t **out) {
-    return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, nullptr,
-                             lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
-                             edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+    return guarded("photon_scene_create", [&]() -> int {
+        return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, nullptr,
+                                 lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                                 edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+    });
 }
 
 int photon_scene_create_from_sources(float lens_pitch, float image_distance, const scattering_data_t *sdp,
@@ -1105,9 +1146,11 @@ int photon_scene_create_from_sources(float lens_pitch, float image_distance, con
         fprintf(stderr, "photon: photon_scene_create_from_sources: null sources\n");
         return 1;
     }
-    return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, sources,
-                             lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
-                             edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+    return guarded("photon_scene_create_from_sources", [&]() -> int {
+        return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, sources,
+                                 lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                                 edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+    });
 }
 
 static int scene_create_impl(float lens_pitch, float image_distance, const scattering_data_t *sdp,
@@ -1187,6 +1230,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         d.train_mode = 0;
         d.ray_order = 0;
         d.src_perm = nullptr;
+        d.source_base = 0;
         d.doom_margin = 0.f;
         s->lens_z = (float)element_center[0][2];
         if ((rc = upload(s, edp, (size_t)num_elements, &d.all_elems))) return bail(rc);
@@ -1270,42 +1314,27 @@ static int end_accumulate(photon_scene *s, float *d_image, hipStream_t stream) {
     return 0;
 }
 
-// One launch group over sources [src_begin, src_end): n rays = sources * rays_per_source.
-// Spatial order of the sources for lens-major launches: Morton code of (x, y) on a 2^16 grid over the
-// sources' bounding box.  Built once per scene, on the host (O(n log n) on 8 n bytes; the sort is not on
-// the per-image path), kept in HBM.
-static int ensure_source_order(photon_scene *s) {
-    if (s->d_perm) return 0;
-    const size_t n = (size_t)s->dev.num_sources;
-    std::vector<float> x(n), y(n);
-    if (n) {
-        PH_CHECK(hipMemcpy(x.data(), s->dev.sx, n * sizeof(float), hipMemcpyDeviceToHost));
-        PH_CHECK(hipMemcpy(y.data(), s->dev.sy, n * sizeof(float), hipMemcpyDeviceToHost));
+// Spatial order of the sources for lens-major launches: Morton code of (x, y) on a 2^16 grid over the bounding
+// box of the LAUNCHED range [src_begin, src_end), sorted on the device (photon_sort.hip) -- start_ray_tracing
+// builds a new scene per call, so this sits on the per-image path of every PIV-through-volume frame (1e6 sources:
+// a host sort cost a D2H of the coordinates, ~0.1 s of std::stable_sort and an H2D per call).  The permutation
+// covers exactly the launched range, so [src_begin, src_end) always counts sources in the CALLER's order,
+// whatever order the lanes then use; it is kept for the next launch of the same range.
+int photon_morton_order(const float *d_x, const float *d_y, int first, long long n, int *d_perm_out, hipStream_t stream);
+
+static int ensure_source_order(photon_scene *s, long long src_begin, long long src_end, hipStream_t stream) {
+    if (s->d_perm && s->perm_begin == src_begin && s->perm_end == src_end) return 0;
+    const size_t n = (size_t)(src_end - src_begin);
+    if (s->perm_capacity < n) {
+        if (s->d_perm) { (void)hipFree(s->d_perm); s->d_perm = nullptr; }
+        s->perm_capacity = 0;
+        PH_CHECK(hipMalloc((void **)&s->d_perm, std::max<size_t>(n, 1) * sizeof(int)));
+        s->perm_capacity = n;
     }
-    float x0 = FLT_MAX, x1 = -FLT_MAX, y0 = FLT_MAX, y1 = -FLT_MAX;
-    for (size_t i = 0; i < n; i++) {
-        if (x[i] < x0) x0 = x[i];
-        if (x[i] > x1) x1 = x[i];
-        if (y[i] < y0) y0 = y[i];
-        if (y[i] > y1) y1 = y[i];
-    }
-    const double fx = x1 > x0 ? 65535.0 / ((double)x1 - x0) : 0.0, fy = y1 > y0 ? 65535.0 / ((double)y1 - y0) : 0.0;
-    auto spread = [](uint32_t v) {                                      // 16 bits -> every other bit of 32
-        v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu;
-        v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
-        return v;
-    };
-    std::vector<std::pair<uint32_t, int>> keyed(n);
-    for (size_t i = 0; i < n; i++) {
-        const double qx = ((double)x[i] - x0) * fx, qy = ((double)y[i] - y0) * fy;
-        const uint32_t ix = qx == qx ? (uint32_t)qx : 0u, iy = qy == qy ? (uint32_t)qy : 0u;     // NaN -> 0
-        keyed[i] = {spread(ix) | (spread(iy) << 1), (int)i};
-    }
-    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) { return a.first < b.first; });
-    std::vector<int> perm(n);
-    for (size_t i = 0; i < n; i++) perm[i] = keyed[i].second;
-    PH_CHECK(hipMalloc((void **)&s->d_perm, std::max<size_t>(n, 1) * sizeof(int)));
-    if (n) PH_CHECK(hipMemcpy(s->d_perm, perm.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    s->perm_begin = s->perm_end = -1;
+    const int rc = photon_morton_order(s->dev.sx, s->dev.sy, (int)src_begin, (long long)n, s->d_perm, stream);
+    if (rc) return rc;
+    s->perm_begin = src_begin; s->perm_end = src_end;
     return 0;
 }
 
@@ -1372,14 +1401,18 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     double *d_image = s->d_acc;
     const unsigned long long n64 = (unsigned long long)(src_end - src_begin) * (unsigned)s->dev.rays_per_source;
     if (n64 == 0) return 0;
-    if (n64 > kMaxRaysPerLaunch) return 1;
+    if (n64 > kMaxRaysPerLaunch) {
+        fprintf(stderr, "photon: a launch of %llu rays (sources [%lld, %lld) x %d) exceeds the %u-ray limit per launch\n", n64,
+                src_begin, src_end, s->dev.rays_per_source, kMaxRaysPerLaunch);
+        return 1;
+    }
     const unsigned n = (unsigned)n64;
     const dim3 block(256), grid((n + 255) / 256);
     s->dev.doom_margin = doom_margin(s, vol, algorithm, dump);
     s->dev.ray_order = 0;
     s->dev.src_perm = nullptr;
     if (use_lens_major(s, vol, dump)) {
-        const int rc = ensure_source_order(s);
+        const int rc = ensure_source_order(s, src_begin, src_end, stream);
         if (rc) return rc;
         s->dev.ray_order = 1;
         s->dev.src_perm = s->d_perm;
@@ -1392,7 +1425,7 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         if (timed) PH_CHECK(hipEventRecord(s->ev[1], stream));
         const int interp = vol->dev.interpolation;
         const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
-        const unsigned long long ray_base = (unsigned long long)src_begin * (unsigned)s->dev.rays_per_source;
+        const unsigned long long ray_base = (unsigned long long)(s->dev.source_base + src_begin) * (unsigned)s->dev.rays_per_source;
         const InterDump idump{dump.inter_pos, dump.inter_dir, dump.inter_slots, dump.num_save, 0u};
         const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
 #define PH_MARCH(A, I, S) hipLaunchKernelGGL((march_kernel<A, I, S>), grid, block, 0, stream, vol->dev, tex, n, s->ws, \
@@ -1427,6 +1460,32 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     return 0;
 }
 
+// The launch loop for sources [src_begin, src_end) into the scene's private f64 accumulator (zeroed first); the
+// caller folds the accumulator into an image (end_accumulate) -- or, when several devices share one call, sums the
+// accumulators first.
+static int trace_accumulate(photon_scene *scene, const photon_volume *vol, int ray_tracing_algorithm, long long src_begin,
+                            long long src_end, hipStream_t stream, bool timed, float *march_ms_out) {
+    const unsigned rps = (unsigned)scene->dev.rays_per_source;
+    if (rps > kMaxRaysPerLaunch) { fprintf(stderr, "photon: too many rays per source\n"); return 1; }
+    const long long max_sources = std::max<long long>(1, kMaxRaysPerLaunch / rps);
+    float march_ms = 0.f;
+    const DumpDev no_dump{nullptr, nullptr, 0, nullptr, nullptr, 0};
+    { const int rc = begin_accumulate(scene, stream); if (rc) return rc; }
+    for (long long b = src_begin; b < src_end; b += max_sources) {
+        const long long e = std::min<long long>(src_end, b + max_sources);
+        const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, no_dump, stream, timed);
+        if (rc) return rc;
+        if (timed && vol) {
+            PH_CHECK(hipEventSynchronize(scene->ev[2]));
+            float ms = 0.f;
+            PH_CHECK(hipEventElapsedTime(&ms, scene->ev[1], scene->ev[2]));
+            march_ms += ms;
+        }
+    }
+    if (march_ms_out) *march_ms_out = march_ms;
+    return 0;
+}
+
 extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_tracing_algorithm,
                             int64_t src_begin, int64_t src_end, float *d_image, void *stream_p,
                             photon_trace_stats_t *stats) {
@@ -1435,47 +1494,35 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
                 (long long)src_end, scene ? scene->dev.num_sources : -1);
         return 1;
     }
-    hipStream_t stream = (hipStream_t)stream_p;
-    const unsigned rps = (unsigned)scene->dev.rays_per_source;
-    const long long max_sources = std::max<long long>(1, kMaxRaysPerLaunch / rps);
-    if (rps > kMaxRaysPerLaunch) { fprintf(stderr, "photon: too many rays per source\n"); return 1; }
-    if (stats) {
-        PH_CHECK(hipMemsetAsync(scene->d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long), stream));
-        PH_CHECK(hipEventRecord(scene->ev[0], stream));
-    }
-    float march_ms = 0.f;
-    const DumpDev no_dump{nullptr, nullptr, 0, nullptr, nullptr, 0};
-    { const int rc = begin_accumulate(scene, stream); if (rc) return rc; }
-    for (long long b = src_begin; b < src_end; b += max_sources) {
-        const long long e = std::min<long long>(src_end, b + max_sources);
-        const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, no_dump, stream, stats != nullptr);
-        if (rc) return rc;
-        if (stats && vol) {
-            PH_CHECK(hipEventSynchronize(scene->ev[2]));
-            float ms = 0.f;
-            PH_CHECK(hipEventElapsedTime(&ms, scene->ev[1], scene->ev[2]));
-            march_ms += ms;
+    return guarded("photon_trace", [&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_p;
+        const unsigned rps = (unsigned)scene->dev.rays_per_source;
+        if (stats) {
+            PH_CHECK(hipMemsetAsync(scene->d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long), stream));
+            PH_CHECK(hipEventRecord(scene->ev[0], stream));
         }
-    }
-    { const int rc = end_accumulate(scene, d_image, stream); if (rc) return rc; }
-    if (stats) {
-        PH_CHECK(hipEventRecord(scene->ev[3], stream));
-        PH_CHECK(hipEventSynchronize(scene->ev[3]));
-        std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
-        PH_CHECK(hipMemcpy(slots.data(), scene->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        unsigned long long c[CNT_N] = {0, 0, 0, 0};
-        for (int k = 0; k < kCounterSlots; k++)
-            for (int j = 0; j < CNT_N; j++) c[j] += slots[(size_t)k * kCounterStride + j];
-        memset(stats, 0, sizeof *stats);
-        stats->rays_launched = (uint64_t)(src_end - src_begin) * rps;
-        stats->rays_on_sensor = c[CNT_ON_SENSOR];
-        stats->rk_iterations = c[CNT_ITER];
-        stats->volume_samples = c[CNT_SAMPLES];
-        stats->sensor_taps = c[CNT_TAPS];
-        stats->march_ms = march_ms;
-        PH_CHECK(hipEventElapsedTime(&stats->total_ms, scene->ev[0], scene->ev[3]));
-    }
-    return 0;
+        float march_ms = 0.f;
+        { const int rc = trace_accumulate(scene, vol, ray_tracing_algorithm, src_begin, src_end, stream, stats != nullptr, &march_ms); if (rc) return rc; }
+        { const int rc = end_accumulate(scene, d_image, stream); if (rc) return rc; }
+        if (stats) {
+            PH_CHECK(hipEventRecord(scene->ev[3], stream));
+            PH_CHECK(hipEventSynchronize(scene->ev[3]));
+            std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
+            PH_CHECK(hipMemcpy(slots.data(), scene->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            unsigned long long c[CNT_N] = {0, 0, 0, 0};
+            for (int k = 0; k < kCounterSlots; k++)
+                for (int j = 0; j < CNT_N; j++) c[j] += slots[(size_t)k * kCounterStride + j];
+            memset(stats, 0, sizeof *stats);
+            stats->rays_launched = (uint64_t)(src_end - src_begin) * rps;
+            stats->rays_on_sensor = c[CNT_ON_SENSOR];
+            stats->rk_iterations = c[CNT_ITER];
+            stats->volume_samples = c[CNT_SAMPLES];
+            stats->sensor_taps = c[CNT_TAPS];
+            stats->march_ms = march_ms;
+            PH_CHECK(hipEventElapsedTime(&stats->total_ms, scene->ev[0], scene->ev[3]));
+        }
+        return 0;
+    });
 }
 
 // =============================================================================================
@@ -1522,14 +1569,25 @@ int ray_order_from_env() {
     return 2;
 }
 
-// PHOTON_TEX_WEIGHTS=exact|fixed8: trilinear weights as exact f32 (default) or as the reference's texture unit
-// holds them (8 fractional bits)
+// PHOTON_TEX_WEIGHTS=fixed8|exact: trilinear weights as the reference's texture unit holds them (8 fractional bits:
+// the documented arithmetic of the tex3D() the reference calls; default) or as exact f32
 int weight_bits_from_env() {
     const char *e = getenv("PHOTON_TEX_WEIGHTS");
-    return e && (strcmp(e, "fixed8") == 0 || strcmp(e, "8") == 0) ? 8 : 0;
+    return e && (strcmp(e, "exact") == 0 || strcmp(e, "0") == 0) ? 0 : 8;
 }
 
-int cached_volume(const char *path, int interpolation, photon_volume **out) {
+// The NRRD of one call, parsed at most once on the host however many devices need it (PHOTON_DEVICES): the
+// first device thread whose cache misses reads the file, the others build their volume from the same array.
+struct SharedDensity {
+    std::once_flag once;
+    bool ok = false;
+    std::string why;
+    std::vector<float> rho;
+    int dims[3] = {0, 0, 0};
+    double spacing[3] = {1, 1, 1}, origin[3] = {0, 0, 0};
+};
+
+int cached_volume(const char *path, int interpolation, photon_volume **out, SharedDensity *shared = nullptr) {
     struct stat st;
     if (stat(path, &st) != 0) {
         fprintf(stderr, "photon: failed to open \"%s\"\n", path);
@@ -1551,7 +1609,18 @@ int cached_volume(const char *path, int interpolation, photon_volume **out) {
     }
     if (c.vol) { photon_volume_free(c.vol); c.vol = nullptr; }
     photon_volume *v = nullptr;
-    const int rc = photon_volume_load_nrrd(path, interpolation, &v);
+    int rc;
+    if (shared) {
+        std::call_once(shared->once, [&]() { shared->ok = parse_nrrd(path, shared->rho, shared->dims, shared->spacing, shared->origin, shared->why); });
+        if (!shared->ok) {
+            fprintf(stderr, "photon: failed to read NRRD \"%s\": %s\n", path, shared->why.c_str());
+            return 2;
+        }
+        rc = photon_volume_from_density(shared->rho.data(), shared->dims[0], shared->dims[1], shared->dims[2], shared->spacing,
+                                        shared->origin, interpolation, &v);
+    } else {
+        rc = photon_volume_load_nrrd(path, interpolation, &v);
+    }
     if (rc) return rc;
     c.path = path; c.mtime_ns = mt; c.size = (long long)st.st_size;
     c.interpolation = interpolation; c.device = device; c.vol = v;
@@ -1595,12 +1664,125 @@ bool write_dump(const char *dir, const char *prefix, int k, const std::vector<fl
     std::ofstream f(full.c_str(), std::ios::out | std::ios::binary);
     if (!f) { fprintf(stderr, "photon: cannot write %s\n", full.c_str()); return false; }
     f.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(v.size() * sizeof(float)));
+    f.flush();
+    if (!f) { fprintf(stderr, "photon: short write to %s\n", full.c_str()); return false; }
     return true;
 }
 
 }  // namespace
 
-extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scattering_data_t *scattering_data_p,
+// acc[i] += other[i] (f64 sensor accumulators of two shards of one call)
+__global__ __launch_bounds__(256) void add_accumulator_kernel(double *__restrict__ acc, const double *__restrict__ other, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += other[i];
+}
+
+namespace {
+
+// Arguments of one start_ray_tracing call, as the multi-device path hands them to its workers.
+struct CallArgs {
+    float lens_pitch, image_distance;
+    scattering_data_t *sdp; char *scattering_type_str; lightfield_source_t *lsp;
+    int rays_per_source; float beam_wavelength, f_number; int num_elements;
+    double (*element_center)[3]; element_data_t *edp; double (*element_planes)[4]; int *sys_index;
+    camera_design_t *cam; bool density; char *density_path; int algorithm;
+    bool add_pos_noise; float pos_noise_std; bool add_ngrad_noise; float ngrad_noise_std; float ratio;
+};
+
+// PHOTON_DEVICES (SURVEY 8e inside ONE call, for photon's single Python process): the sources are cut into
+// contiguous, count-balanced blocks, one per listed device; each device thread uploads ONLY its block (plus the
+// replicated tables, optics and volume -- the NRRD is parsed once, SharedDensity), renders into its scene's private
+// f64 accumulator, and the accumulators are then summed ON THE DEVICES: device k's accumulator travels to the first
+// device by hipMemcpyPeer (xGMI when peer access is available) and is added there by a kernel, in device-list order;
+// one finalize folds the sum into the caller's image.  Summation stays f64 end to end, one rounding per pixel.
+int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float *image_array) {
+    const char *e = getenv("PHOTON_NOISE_SEED");
+    const uint64_t seed = e ? strtoull(e, nullptr, 0) : 0x5eedULL;
+    const long long n_src = a.lsp->num_particles;
+    const size_t npix = (size_t)a.cam->x_pixel_number * a.cam->y_pixel_number;
+    const size_t K = devices.size();
+    std::vector<photon_scene *> scenes(K, nullptr);
+    std::vector<int> rcs(K, 0);
+    SharedDensity shared;
+    std::vector<std::thread> workers;
+    for (size_t k = 0; k < K; k++) {
+        workers.emplace_back([&, k]() {
+            rcs[k] = guarded("start_ray_tracing (device worker)", [&]() -> int {
+                const long long b = n_src * (long long)k / (long long)K, e2 = n_src * (long long)(k + 1) / (long long)K;
+                if (hipSetDevice(devices[k]) != hipSuccess) return 1;
+                lightfield_source_t shard = *a.lsp;                     // this device's block of the caller's arrays
+                shard.x += b; shard.y += b; shard.z += b; shard.radiance += b; shard.diameter_index += b;
+                shard.num_particles = (int)(e2 - b);
+                photon_scene *sc = nullptr;
+                if (photon_scene_create(a.lens_pitch, a.image_distance, a.sdp, a.scattering_type_str, &shard, a.rays_per_source,
+                                        a.beam_wavelength, a.f_number, a.num_elements, a.element_center, a.edp, a.element_planes,
+                                        a.sys_index, a.cam, a.ratio, &sc)) return 2;
+                scenes[k] = sc;
+                sc->dev.source_base = b;
+                photon_scene_set_noise(sc, a.add_pos_noise, a.pos_noise_std, a.density && a.add_ngrad_noise, a.ngrad_noise_std, seed);
+                photon_scene_set_element_train(sc, element_train_from_env());
+                photon_scene_set_ray_order(sc, ray_order_from_env());
+                photon_scene_set_skip_doomed(sc, skip_doomed_from_env());
+                photon_volume *v = nullptr;
+                int rc = 0;
+                if (a.density) rc = cached_volume(a.density_path, interpolation_from_env(), &v, &shared);
+                if (!rc && v) photon_volume_set_weight_bits(v, weight_bits_from_env());
+                if (!rc) rc = trace_accumulate(sc, v, a.algorithm, 0, e2 - b, nullptr, false, nullptr);
+                if (!rc && hipDeviceSynchronize() != hipSuccess) rc = 4;
+                return rc;
+            });
+        });
+    }
+    for (auto &w : workers) w.join();
+    int rc = 0;
+    for (size_t k = 0; k < K && !rc; k++)
+        if (rcs[k]) { fprintf(stderr, "photon: device %d failed (%d); image left untouched\n", devices[k], rcs[k]); rc = rcs[k]; }
+    // reduce onto the first device, fold into the caller's image there
+    {
+        DeviceBuffer<double> d_peer;
+        DeviceBuffer<float> d_img;
+        auto check = [&](hipError_t err, int line) {
+            if (err != hipSuccess && !rc) {
+                fprintf(stderr, "photon: HIP error %d (%s) at %s:%d; image left untouched\n", (int)err, hipGetErrorString(err), __FILE__, line);
+                rc = (int)err;
+            }
+            return rc == 0;
+        };
+        if (!rc && check(hipSetDevice(devices[0]), __LINE__)) {
+            const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
+            for (size_t k = 1; k < K && !rc; k++) {
+                const double *other = scenes[k]->d_acc;
+                if (devices[k] != devices[0]) {
+                    if (!d_peer.p && !check(d_peer.alloc(npix), __LINE__)) break;
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) == hipSuccess && can) {
+                        const hipError_t pe = hipDeviceEnablePeerAccess(devices[k], 0);     // direct xGMI copies; already-enabled is fine
+                        if (pe != hipSuccess) (void)hipGetLastError();
+                    }
+                    if (!check(hipMemcpyPeer(d_peer.p, devices[0], other, devices[k], npix * sizeof(double)), __LINE__)) break;
+                    other = d_peer.p;
+                }
+                hipLaunchKernelGGL(add_accumulator_kernel, grid, block, 0, 0, scenes[0]->d_acc, other, npix);
+                if (!check(hipGetLastError(), __LINE__)) break;
+                if (!check(hipDeviceSynchronize(), __LINE__)) break;        // d_peer is reused by the next device
+            }
+            if (!rc && check(d_img.alloc(npix), __LINE__) &&
+                check(hipMemcpy(d_img.p, image_array, npix * sizeof(float), hipMemcpyHostToDevice), __LINE__)) {     // .cu:3309
+                const int frc = end_accumulate(scenes[0], d_img.p, nullptr);
+                if (frc && !rc) rc = frc;
+                if (!rc && check(hipDeviceSynchronize(), __LINE__))
+                    check(hipMemcpy(image_array, d_img.p, npix * sizeof(float), hipMemcpyDeviceToHost), __LINE__);      // .cu:3675
+            }
+        }
+    }
+    for (size_t k = 0; k < K; k++)
+        if (scenes[k]) { (void)hipSetDevice(devices[k]); photon_scene_free(scenes[k]); }
+    return rc;
+}
+
+}  // namespace
+
+static void start_ray_tracing_impl(float lens_pitch, float image_distance, scattering_data_t *scattering_data_p,
                                   char *scattering_type_str, lightfield_source_t *lightfield_source_p,
                                   int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
                                   int num_elements, double (*element_center)[3], element_data_t *element_data_p,
@@ -1618,72 +1800,24 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
         return;
     }
     const bool dumping = save_lightrays && num_lightrays_save > 0;
-    {   // PHOTON_DEVICES: shard the sources over several GPUs inside this one call.  Ray dumps
-        // keep the reference's chunk -> file mapping and stay on one device.
+    int caller_device = 0;                                              // the caller's current device is restored on every path
+    const bool have_caller_device = hipGetDevice(&caller_device) == hipSuccess;
+    struct RestoreDevice { bool on; int dev; ~RestoreDevice() { if (on) (void)hipSetDevice(dev); } } restore{have_caller_device, caller_device};
+    {   // PHOTON_DEVICES: shard the sources of one call over several GPUs.  Ray dumps keep the
+        // reference's chunk -> file mapping and stay on one device.
         const std::vector<int> devices = devices_from_env();
         if (devices.size() > 1 && !dumping) {
-            const char *e = getenv("PHOTON_NOISE_SEED");
-            const uint64_t seed = e ? strtoull(e, nullptr, 0) : 0x5eedULL;
-            const long long n_src = lightfield_source_p->num_particles;
-            const size_t npix = (size_t)camera_design_p->x_pixel_number * camera_design_p->y_pixel_number;
-            const size_t K = devices.size();
-            std::vector<std::vector<float>> partial(K);
-            std::vector<int> rcs(K, 0);
-            std::vector<std::thread> workers;
-            for (size_t k = 0; k < K; k++) {
-                workers.emplace_back([&, k]() {
-                    // contiguous blocks of sources, balanced by count (all sources carry the same number of rays)
-                    const long long b = n_src * (long long)k / (long long)K, e2 = n_src * (long long)(k + 1) / (long long)K;
-                    rcs[k] = [&]() -> int {
-                        if (hipSetDevice(devices[k]) != hipSuccess) return 1;
-                        photon_scene *sc = nullptr;
-                        if (photon_scene_create(lens_pitch, image_distance, scattering_data_p, scattering_type_str,
-                                                lightfield_source_p, lightray_number_per_particle, beam_wavelength,
-                                                aperture_f_number, num_elements, element_center, element_data_p,
-                                                element_plane_parameters, element_system_index, camera_design_p,
-                                                ray_cone_pitch_ratio, &sc)) return 2;
-                        photon_scene_set_noise(sc, add_pos_noise, pos_noise_std, simulate_density_gradients && add_ngrad_noise,
-                                               ngrad_noise_std, seed);
-                        photon_scene_set_element_train(sc, element_train_from_env());
-                        photon_scene_set_ray_order(sc, ray_order_from_env());
-                        photon_scene_set_skip_doomed(sc, skip_doomed_from_env());
-                        photon_volume *v = nullptr;
-                        float *d_img = nullptr;
-                        int rc = 0;
-                        if (simulate_density_gradients) rc = cached_volume(density_grad_filename, interpolation_from_env(), &v);
-                        if (!rc && v) photon_volume_set_weight_bits(v, weight_bits_from_env());
-                        if (!rc && hipMalloc((void **)&d_img, npix * sizeof(float)) != hipSuccess) rc = 3;
-                        if (!rc && hipMemset(d_img, 0, npix * sizeof(float)) != hipSuccess) rc = 3;
-                        if (!rc) rc = photon_trace(sc, v, ray_tracing_algorithm, b, e2, d_img, nullptr, nullptr);
-                        if (!rc && hipDeviceSynchronize() != hipSuccess) rc = 4;
-                        if (!rc) {
-                            partial[k].resize(npix);
-                            if (hipMemcpy(partial[k].data(), d_img, npix * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = 4;
-                        }
-                        if (d_img) (void)hipFree(d_img);
-                        photon_scene_free(sc);
-                        return rc;
-                    }();
-                });
-            }
-            for (auto &w : workers) w.join();
-            for (size_t k = 0; k < K; k++) {
-                if (rcs[k]) {
-                    fprintf(stderr, "photon: device %d failed (%d); image left untouched\n", devices[k], rcs[k]);
-                    return;
-                }
-            }
-            // the only shared state of the path is this sum: incoming image + the private images,
-            // added in device-list order in double, rounded once
-            for (size_t i = 0; i < npix; i++) {
-                double acc = (double)image_array[i];
-                for (size_t k = 0; k < K; k++) acc += (double)partial[k][i];
-                image_array[i] = (float)acc;
-            }
-            if (verbose()) {
+            const CallArgs a{lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
+                             lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                             element_data_p, element_plane_parameters, element_system_index, camera_design_p,
+                             simulate_density_gradients, density_grad_filename, ray_tracing_algorithm, add_pos_noise,
+                             pos_noise_std, add_ngrad_noise, ngrad_noise_std, ray_cone_pitch_ratio};
+            const int rc = render_on_devices(devices, a, image_array);
+            if (!rc && verbose()) {
                 const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                const long long n_src = lightfield_source_p->num_particles;
                 printf("photon: %lld sources x %d rays on %zu devices in %.3f s (%.2f Mrays/s incl. transfers)\n", n_src,
-                       lightray_number_per_particle, K, sec, n_src * (double)lightray_number_per_particle / sec * 1e-6);
+                       lightray_number_per_particle, devices.size(), sec, n_src * (double)lightray_number_per_particle / sec * 1e-6);
             }
             return;
         }
@@ -1769,16 +1903,18 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
             rc = launch_chunk(scene, vol, ray_tracing_algorithm, k * chunk, std::min(num_particles, (k + 1) * chunk),
                               dump, nullptr, false);
             if (rc) break;
+            bool wrote = true;                                          // a dump that cannot be written fails the call
             PH_VOID(hipMemcpy(host.data(), d_fpos, nsave * sizeof(float), hipMemcpyDeviceToHost));
-            write_dump(lightray_position_save_path, "pos_", (int)k, host);
+            wrote = write_dump(lightray_position_save_path, "pos_", (int)k, host) && wrote;
             PH_VOID(hipMemcpy(host.data(), d_fdir, nsave * sizeof(float), hipMemcpyDeviceToHost));
-            write_dump(lightray_direction_save_path, "dir_", (int)k, host);
+            wrote = write_dump(lightray_direction_save_path, "dir_", (int)k, host) && wrote;
             if (inter) {
                 PH_VOID(hipMemcpy(host_inter.data(), d_ipos, ninter * sizeof(float), hipMemcpyDeviceToHost));
-                write_dump(lightray_position_save_path, "intermediate_pos_", (int)k, host_inter);
+                wrote = write_dump(lightray_position_save_path, "intermediate_pos_", (int)k, host_inter) && wrote;
                 PH_VOID(hipMemcpy(host_inter.data(), d_idir, ninter * sizeof(float), hipMemcpyDeviceToHost));
-                write_dump(lightray_direction_save_path, "intermediate_dir_", (int)k, host_inter);
+                wrote = write_dump(lightray_direction_save_path, "intermediate_dir_", (int)k, host_inter) && wrote;
             }
+            if (!wrote) rc = 5;
         }
         if (rc == 0) rc = end_accumulate(scene, d_image, nullptr);
     } else {
@@ -1801,4 +1937,29 @@ extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scatte
         printf("photon: %lld sources x %lld rays in %.3f s (%.2f Mrays/s incl. transfers)\n", num_particles, rps, s,
                num_particles * rps / s * 1e-6);
     }
+}
+
+// The exported symbol: no C++ exception crosses the C boundary.
+extern "C" void start_ray_tracing(float lens_pitch, float image_distance, scattering_data_t *scattering_data_p,
+                                  char *scattering_type_str, lightfield_source_t *lightfield_source_p,
+                                  int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
+                                  int num_elements, double (*element_center)[3], element_data_t *element_data_p,
+                                  double (*element_plane_parameters)[4], int *element_system_index,
+                                  camera_design_t *camera_design_p, float *image_array,
+                                  bool simulate_density_gradients, char *density_grad_filename, bool save_lightrays,
+                                  char *lightray_position_save_path, char *lightray_direction_save_path,
+                                  int num_lightrays_save, int ray_tracing_algorithm, bool add_pos_noise,
+                                  float pos_noise_std, bool add_ngrad_noise, float ngrad_noise_std,
+                                  float ray_cone_pitch_ratio, bool save_intermediate_ray_data,
+                                  int num_intermediate_positions_save) {
+    (void)guarded("start_ray_tracing", [&]() -> int {
+        start_ray_tracing_impl(lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
+                               lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                               element_data_p, element_plane_parameters, element_system_index, camera_design_p, image_array,
+                               simulate_density_gradients, density_grad_filename, save_lightrays, lightray_position_save_path,
+                               lightray_direction_save_path, num_lightrays_save, ray_tracing_algorithm, add_pos_noise,
+                               pos_noise_std, add_ngrad_noise, ngrad_noise_std, ray_cone_pitch_ratio,
+                               save_intermediate_ray_data, num_intermediate_positions_save);
+        return 0;
+    });
 }

@@ -1,0 +1,106 @@
+// photon_sort.hip - spatial (Morton) order of a range of light-field sources, built on the device.
+//
+// Lens-major launches (photon_core.hip, "Ray order") put 64 neighbouring sources aimed at one lens point into
+// a wave; "neighbouring" = consecutive in the Morton order of (x, y) on a 2^16 x 2^16 grid over the range's
+// bounding box.  start_ray_tracing builds a new scene on every call, so the order is on the per-image path of
+// every PIV-through-volume frame: it is computed where the sources already are (HBM) -- bounding box by a
+// block reduce + ordered-integer atomics, keys, then a stable LSD radix sort of (key, index) pairs (rocPRIM via
+// hipCUB: a utility off the hot path; stable, so equal keys keep the caller's order and the permutation is
+// deterministic) -- with no host round trip of the coordinates.  Speed only: the image is a sum over sources.
+//
+// Own translation unit: the sort's templates do not ride in the march kernels' compile.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+
+namespace {
+
+// order-preserving map float -> uint32 (NaN never enters: filtered by the caller of enc)
+__device__ __forceinline__ unsigned enc(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec(unsigned e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+// box[0..3] = enc(min x), enc(max x), enc(min y), enc(max y); initialised to {~0, 0, ~0, 0}
+__global__ __launch_bounds__(256) void bbox_kernel(const float *__restrict__ x, const float *__restrict__ y, long long n,
+                                                   unsigned *box) {
+    unsigned lo_x = 0xffffffffu, hi_x = 0u, lo_y = 0xffffffffu, hi_y = 0u;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float xv = x[i], yv = y[i];
+        if (xv == xv) { const unsigned e = enc(xv); lo_x = min(lo_x, e); hi_x = max(hi_x, e); }
+        if (yv == yv) { const unsigned e = enc(yv); lo_y = min(lo_y, e); hi_y = max(hi_y, e); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo_x = min(lo_x, (unsigned)__shfl_xor((int)lo_x, o, 64)); hi_x = max(hi_x, (unsigned)__shfl_xor((int)hi_x, o, 64));
+        lo_y = min(lo_y, (unsigned)__shfl_xor((int)lo_y, o, 64)); hi_y = max(hi_y, (unsigned)__shfl_xor((int)hi_y, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&box[0], lo_x); atomicMax(&box[1], hi_x);
+        atomicMin(&box[2], lo_y); atomicMax(&box[3], hi_y);
+    }
+}
+
+__device__ __forceinline__ unsigned spread16(unsigned v) {              // 16 bits -> every other bit of 32
+    v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void morton_keys_kernel(const float *__restrict__ x, const float *__restrict__ y, long long n,
+                                                          const unsigned *__restrict__ box, int first, unsigned *keys, int *idx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = dec(box[0]), x1 = dec(box[1]), y0 = dec(box[2]), y1 = dec(box[3]);
+    const double fx = x1 > x0 ? 65535.0 / ((double)x1 - x0) : 0.0, fy = y1 > y0 ? 65535.0 / ((double)y1 - y0) : 0.0;
+    const double qx = ((double)x[i] - x0) * fx, qy = ((double)y[i] - y0) * fy;
+    const unsigned ix = qx == qx ? (unsigned)qx : 0u, iy = qy == qy ? (unsigned)qy : 0u;    // NaN -> 0
+    keys[i] = spread16(ix & 0xffffu) | (spread16(iy & 0xffffu) << 1);
+    idx[i] = first + (int)i;
+}
+
+}  // namespace
+
+// perm_out[k] (device, n entries) = index, in the CALLER's source numbering, of the k-th source of
+// [first, first + n) in Morton order.  x, y: device pointers to the whole source arrays.  Asynchronous on
+// `stream` except for the temporary allocations.  Returns 0 or a HIP error code.
+int photon_morton_order(const float *d_x, const float *d_y, int first, long long n, int *d_perm_out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    unsigned *d_box = nullptr, *d_keys = nullptr, *d_keys_out = nullptr;
+    int *d_idx = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipError_t e = hipSuccess;
+    auto done = [&](hipError_t err, int line) {
+        if (err != hipSuccess) fprintf(stderr, "photon: HIP error %d (%s) at %s:%d\n", (int)err, hipGetErrorString(err), __FILE__, line);
+        if (d_box) (void)hipFree(d_box);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_idx) (void)hipFree(d_idx);
+        if (d_tmp) (void)hipFree(d_tmp);
+        return (int)err;
+    };
+#define PS_CHECK(expr) do { e = (expr); if (e != hipSuccess) return done(e, __LINE__); } while (0)
+    PS_CHECK(hipMalloc((void **)&d_box, 4 * sizeof(unsigned)));
+    PS_CHECK(hipMalloc((void **)&d_keys, 2 * (size_t)n * sizeof(unsigned)));
+    d_keys_out = d_keys + n;
+    PS_CHECK(hipMalloc((void **)&d_idx, (size_t)n * sizeof(int)));
+    const unsigned init[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
+    PS_CHECK(hipMemcpyAsync(d_box, init, sizeof init, hipMemcpyHostToDevice, stream));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, stream, d_x + first, d_y + first, n, d_box);
+    PS_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(morton_keys_kernel, dim3(blocks), dim3(256), 0, stream, d_x + first, d_y + first, n, d_box, first, d_keys, d_idx);
+    PS_CHECK(hipGetLastError());
+    PS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_out, d_idx, d_perm_out, (int)n, 0, 32, stream));
+    PS_CHECK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    PS_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_out, d_idx, d_perm_out, (int)n, 0, 32, stream));
+    PS_CHECK(hipStreamSynchronize(stream));         // the temporaries die here
+#undef PS_CHECK
+    return done(hipSuccess, 0);
+}

@@ -55,9 +55,15 @@ def _ptr(a: np.ndarray):
 class PhotonLibrary:
     def __init__(self, path: Optional[str] = None, build: bool = True):
         if path is None:
-            path = os.environ.get("PHOTON_LIBRARY") or _build.LIB_PATH
-            if build and not os.path.exists(path):
-                _build.build_library()
+            path = os.environ.get("PHOTON_LIBRARY")
+            if not path:                    # the in-tree library: (re)built when missing or older than its sources
+                path = _build.LIB_PATH
+                if build:
+                    try:
+                        _build.build_library(verbose=False)
+                    except Exception as e:  # no hipcc on this box: a library that travelled with the tree is used as is
+                        if not os.path.exists(path):
+                            raise PhotonError(f"cannot build {path}: {e}") from e
         if not os.path.exists(path):
             raise PhotonError(f"{path} not found: build it with `python -m photon_amd.build` "
                               "(there is no CPU fallback)")

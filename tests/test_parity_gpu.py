@@ -665,6 +665,15 @@ def test_in_library_device_sharding(photon, oracle, small_volume_file, monkeypat
     assert rel_l2(photon.render(call), single) <= IMAGE_TOL
     monkeypatch.setenv("PHOTON_DEVICES", "0,99")                 # a device that is not there: falls back, says so
     assert rel_l2(photon.render(call), single) <= IMAGE_TOL
+    # each device uploads only its block of the sources; the noise generator is keyed by the ray's place in the
+    # CALLER's source list, so the shards draw the same numbers as the single pass
+    call.add_pos_noise, call.pos_noise_std = True, 0.4
+    monkeypatch.setenv("PHOTON_NOISE_SEED", "7")
+    monkeypatch.delenv("PHOTON_DEVICES")
+    noisy = photon.render(call)
+    assert rel_l2(noisy, single) > 1e-3                          # the noise does something
+    monkeypatch.setenv("PHOTON_DEVICES", "0,0,0")
+    assert rel_l2(photon.render(call), noisy) <= IMAGE_TOL
 
 
 def test_doomed_rays_are_skipped_not_missed(photon, oracle, small_volume_file, monkeypatch):
