@@ -138,6 +138,40 @@ class Oracle:
                                             int(tex_frac_bits))
         return OracleVolume(self, h)
 
+    # ---- single device functions, for the reference-derived pins ------------------------------
+    def generate_rays(self, call: RayTracingCall, source: int, r1, r2):
+        """Rays of one source for explicit lens samples (r1, r2): pos/dir [n][3] f32, radiance [n] f64
+        (generate_lightfield_angular_data, parallel_ray_tracing.cu:71-237)."""
+        sd, ls, elems, centers, planes, sysidx, cam = call.pack()
+        r1 = np.ascontiguousarray(r1, dtype=np.float32)
+        r2 = np.ascontiguousarray(r2, dtype=np.float32)
+        n = r1.size
+        pos, direction, rad = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.float64)
+        f = self.lib.oracle_generate_rays
+        f.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                      ctypes.c_float, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        f(call.lens_pitch, call.image_distance, ctypes.addressof(sd), 1 if call.scattering_type == "mie" else 0,
+          float(np.float32(call.src_x[source])), float(np.float32(call.src_y[source])), float(np.float32(call.src_z[source])),
+          float(call.src_radiance[source]), int(call.src_diameter_index[source]), n, call.beam_wavelength,
+          call.aperture_f_number, _p(r1), _p(r2), call.ray_cone_pitch_ratio, _p(pos), _p(direction), _p(rad))
+        return pos, direction, rad
+
+    def pixel_taps(self, camera: dict, x, y):
+        """Pixel indices ii/jj [n][4], area weights [n][4] and inside flags of sensor hits (x, y)
+        (intersect_sensor, parallel_ray_tracing.cu:1803-1880)."""
+        from photon_amd.ray_tracing import camera_from_dict
+        cam = camera_from_dict(camera)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        n = x.size
+        ii, jj = np.empty((n, 4), np.int32), np.empty((n, 4), np.int32)
+        w, inside = np.empty((n, 4), np.float64), np.empty(n, np.int32)
+        f = self.lib.oracle_pixel_taps
+        f.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7
+        f(n, _p(x), _p(y), ctypes.addressof(cam), _p(ii), _p(jj), _p(w), _p(inside))
+        return ii, jj, w, inside.astype(bool)
+
     # ---- scene generation -----------------------------------------------------------------
     def sources_bos(self, dot_xy, template_xy, z, radiance):
         d = np.ascontiguousarray(dot_xy, dtype=np.float64).reshape(-1, 2)

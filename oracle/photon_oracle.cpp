@@ -1175,20 +1175,17 @@ f3 apparent_image(Image &img, const Ray &ray, const camera_design_t &cam, float 
     return hit;
 }
 
-// intersect_sensor + the 4-pixel splat loop, parallel_ray_tracing.cu:1735-1895, :2199-2234
-f3 sensor_bilinear(Image &img, const Ray &ray, const camera_design_t &cam, const Noise &nz, uint64_t ray_id) {
-    const float t = sensor_time(ray.pos, ray.dir, 0.0f, 0.0f, 1.0f, -cam.z_sensor);
-    f3 hit = ray.pos + ray.dir * t;
-    add_position_noise(hit, cam, nz, ray_id);                           // .cu:1773-1783
-    const f3 dir = ray.dir;
-    const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
-    const double cos4 = photon_det_cosf(alpha) * photon_det_cosf(alpha) * photon_det_cosf(alpha) * photon_det_cosf(alpha);
+// The four pixels a sensor hit is shared between and their area weights, parallel_ray_tracing.cu:1803-1880
+// (no x flip, no MATLAB-style +1.5 offset: that is the numpy ancestor's, perform_ray_tracing_03.py:1505-1506).
+struct PixelTaps { bool inside; int ii[4], jj[4]; double w[4]; };
+PixelTaps pixel_taps(f3 hit, const camera_design_t &cam) {
+    PixelTaps t{};
     const float p1x = (float)(-cam.pixel_pitch * (cam.x_pixel_number - 1) / 2.0);
     const float p1y = (float)(-cam.pixel_pitch * (cam.y_pixel_number - 1) / 2.0);
     const float d_x = (hit.x - p1x) / cam.pixel_pitch;
     const float d_y = (hit.y - p1y) / cam.pixel_pitch;
-    if (d_x >= cam.x_pixel_number || d_y >= cam.y_pixel_number || d_x < 0 || d_y < 0)
-        return mk3(NANF, NANF, NANF);
+    t.inside = !(d_x >= cam.x_pixel_number || d_y >= cam.y_pixel_number || d_x < 0 || d_y < 0);
+    if (!t.inside) return t;
     const float d_y_lower = d_y - 0.5, d_x_lower = d_x - 0.5;
     const double d_ii_ul = ceilf(d_y_lower) - d_y_lower;                // float op stored in double
     const double d_jj_ul = ceilf(d_x_lower) - d_x_lower;
@@ -1197,6 +1194,22 @@ f3 sensor_bilinear(Image &img, const Ray &ray, const camera_design_t &cam, const
     const int ii_ul = (int)(ceilf(d_y_lower) - 1), jj_ul = (int)(ceilf(d_x_lower) - 1);
     const int ii[4] = {ii_ul, ii_ul, ii_ul + 1, ii_ul + 1};
     const int jj[4] = {jj_ul, jj_ul + 1, jj_ul, jj_ul + 1};
+    for (int k = 0; k < 4; k++) { t.ii[k] = ii[k]; t.jj[k] = jj[k]; t.w[k] = w[k]; }
+    return t;
+}
+
+// intersect_sensor + the 4-pixel splat loop, parallel_ray_tracing.cu:1735-1895, :2199-2234
+f3 sensor_bilinear(Image &img, const Ray &ray, const camera_design_t &cam, const Noise &nz, uint64_t ray_id) {
+    const float t = sensor_time(ray.pos, ray.dir, 0.0f, 0.0f, 1.0f, -cam.z_sensor);
+    f3 hit = ray.pos + ray.dir * t;
+    add_position_noise(hit, cam, nz, ray_id);                           // .cu:1773-1783
+    const f3 dir = ray.dir;
+    const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
+    const double cos4 = photon_det_cosf(alpha) * photon_det_cosf(alpha) * photon_det_cosf(alpha) * photon_det_cosf(alpha);
+    const PixelTaps px = pixel_taps(hit, cam);
+    if (!px.inside) return mk3(NANF, NANF, NANF);
+    const int *ii = px.ii, *jj = px.jj;
+    const double *w = px.w;
     const int W = cam.x_pixel_number, H = cam.y_pixel_number;
     for (int k = 0; k < 4; k++) {
         if (ii[k] < 0 || ii[k] >= H || jj[k] < 0 || jj[k] >= W) continue;          // :2223
@@ -1566,6 +1579,16 @@ void oracle_generate_rays(float lens_pitch, float image_distance, scattering_dat
         pos[3 * k] = r.pos.x; pos[3 * k + 1] = r.pos.y; pos[3 * k + 2] = r.pos.z;
         dir[3 * k] = r.dir.x; dir[3 * k + 1] = r.dir.y; dir[3 * k + 2] = r.dir.z;
         radiance[k] = r.radiance;
+    }
+}
+
+// pixel indices and area weights of n sensor hits (x, y): ii/jj int[n][4], w double[n][4], inside int[n]
+void oracle_pixel_taps(int n, const float *x, const float *y, const camera_design_t *cam, int *ii, int *jj, double *w,
+                       int *inside) {
+    for (int k = 0; k < n; k++) {
+        const PixelTaps t = pixel_taps(mk3(x[k], y[k], cam->z_sensor), *cam);
+        inside[k] = t.inside;
+        for (int q = 0; q < 4; q++) { ii[4 * k + q] = t.ii[q]; jj[4 * k + q] = t.jj[q]; w[4 * k + q] = t.w[q]; }
     }
 }
 

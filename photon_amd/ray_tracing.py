@@ -346,6 +346,19 @@ def camera_from_dict(c: dict) -> camera_design_struct:
 # ----------------------------------------------------------------------------------------------
 
 
+def calculate_rotation_matrix(theta_x: float, theta_y: float, theta_z: float = 0.0) -> np.ndarray:
+    """World -> camera rotation of photon's driver (run_simulation_02.py:366-392): R = Rx . Ry . Rz with the
+    reference's sign convention; camera_design's `rotation_matrix` is this for (x_camera_angle, y_camera_angle, 0)
+    and `inverse_rotation_matrix` its transpose (:1748-1753).  Pinned against the reference's outputs
+    (tests/golden/pins.npz)."""
+    cx, sx, cy, sy, cz, sz = (np.cos(theta_x), np.sin(theta_x), np.cos(theta_y), np.sin(theta_y), np.cos(theta_z),
+                              np.sin(theta_z))
+    rx = np.array([[1.0, 0.0, 0.0], [0.0, cx, sx], [0.0, -sx, cx]])
+    ry = np.array([[cy, 0.0, -sy], [0.0, 1.0, 0.0], [sy, 0.0, cy]])
+    rz = np.array([[cz, sz, 0.0], [-sz, cz, 0.0], [0.0, 0.0, 1.0]])
+    return rx @ ry @ rz
+
+
 def single_lens_camera(focal_length: float, aperture_f_number: float, object_distance: float,
                        lens_radius_of_curvature: float, lens_model: str = "general") -> dict:
     f, R = float(focal_length), float(lens_radius_of_curvature)

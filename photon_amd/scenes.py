@@ -111,6 +111,24 @@ def sunflower_disc(n_points: int, diameter: float) -> np.ndarray:
     return np.stack([r * np.cos(t), r * np.sin(t)], 1)
 
 
+def concentric_disc(diameter: float, n_points: float, phases) -> np.ndarray:
+    """The reference's BOS dot template (calculate_sunflower_coordinates, run_simulation_02.py:999-1056): points on
+    concentric circles one nearest-neighbour spacing apart, each circle turned by 2 pi * phases[k] (the reference
+    draws that phase from numpy's global generator), plus the centre -> [n, 2].  Note the reference's own quirk:
+    a circle meant to carry m points gets m - 1 (np.arange(1, m) - 1).  Pinned by tests/golden/pins.npz."""
+    area = np.pi * (diameter / 2.0) ** 2.0
+    spacing = np.sqrt(area / n_points)
+    radii = np.linspace(spacing, diameter / 2.0, int(np.round((diameter / 2.0) / spacing)))
+    rho = 1.0 / spacing
+    xs, ys = [], []
+    for k, r in enumerate(radii):
+        m = np.round(rho * (2.0 * np.pi * r))
+        theta = (2.0 * np.pi / m) * (np.arange(1.0, m) - 1.0) + 2.0 * np.pi * float(phases[k])
+        xs.append(r * np.cos(theta))
+        ys.append(r * np.sin(theta))
+    return np.stack([np.append(np.concatenate(xs), 0.0), np.append(np.concatenate(ys), 0.0)], 1)
+
+
 def _call(cam_geom, camera, **kw) -> RayTracingCall:
     return RayTracingCall(
         lens_pitch=cam_geom["lens_pitch"], image_distance=cam_geom["image_distance"],

@@ -36,6 +36,11 @@ def photon():
     from photon_amd.library import PhotonLibrary
     if not os.path.exists("/dev/kfd"):
         pytest.skip("no GPU in this environment (/dev/kfd absent)")
+    # torch first: several tests hand torch device tensors to the library, and a process must run ONE HIP runtime.
+    # torch bundles its own libamdhip64; loaded first, the library (RUNPATH /opt/rocm/lib) binds to that copy by
+    # SONAME instead of mapping the system's next to it (two runtimes in one process: torch then finds no device).
+    import torch
+    assert torch.cuda.is_available(), "a GPU device node exists but torch sees no device"
     lib = PhotonLibrary()
     lib.set_device(0)               # raises if HIP cannot reach the device: a broken runtime must not go green
     return lib

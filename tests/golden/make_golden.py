@@ -183,6 +183,24 @@ def run_case(case, shrink):
 
     rs.perform_ray_tracing_03 = wrapped
 
+    # the BOS generator's own intermediate results (run_simulation_02.py:1328-1551, 999-1056): dot centres and the
+    # sunflower point template whose sums are the source coordinates
+    extra = {}
+    orig_sun, orig_bos = rs.calculate_sunflower_coordinates, rs.generate_bos_lightfield_data
+
+    def sun_wrapped(*a, **k):
+        xy = orig_sun(*a, **k)
+        extra["tmpl_x"], extra["tmpl_y"] = np.array(xy[0], dtype=np.float64).ravel(), np.array(xy[1], dtype=np.float64).ravel()
+        extra["tmpl_args"] = np.array([float(a[0]), float(a[1])])
+        return xy
+
+    def bos_wrapped(*a, **k):
+        src, gx, gy = orig_bos(*a, **k)
+        extra["dot_x"], extra["dot_y"] = np.array(gx, dtype=np.float64).ravel(), np.array(gy, dtype=np.float64).ravel()
+        return src, gx, gy
+
+    rs.calculate_sunflower_coordinates, rs.generate_bos_lightfield_data = sun_wrapped, bos_wrapped
+
     # --- what batch_run_simulation.py:71-115 does, minus argv ---
     m = sio.loadmat(os.path.join(REF, "sample-data", case, "parameters", "sample-parameters.mat"),
                     struct_as_record=False, squeeze_me=True)
@@ -200,13 +218,16 @@ def run_case(case, shrink):
     shrink(p)
     rs.run_simulation_02(p)
     rs.perform_ray_tracing_03 = orig
+    rs.calculate_sunflower_coordinates, rs.generate_bos_lightfield_data = orig_sun, orig_bos
+    for c in rec.calls:
+        c[1].update(extra)
     os.chdir = real_chdir
     os.chdir(OUT)
     shutil.rmtree(work, ignore_errors=True)
     return rec.calls, post, p
 
 
-def save_case(name, call, post, params):
+def save_case(name, call, post, params, sources_only=False):
     rec, arrays = call
     cd = params["camera_design"]
     rec["postprocess"] = dict(pixel_gain=float(cd["pixel_gain"]),
@@ -219,6 +240,8 @@ def save_case(name, call, post, params):
         json.dump(rec, f, indent=1, sort_keys=True, default=float)
     synth = arrays.pop("synthetic_image")
     np.savez_compressed(os.path.join(OUT, f"abi_{name}.npz"), **arrays)
+    if sources_only:
+        return
     I, I_raw = post
     nz = np.flatnonzero(synth)
     np.savez_compressed(os.path.join(OUT, f"postprocess_{name}.npz"),
@@ -284,6 +307,64 @@ def lens_golden():
     np.savez_compressed(os.path.join(OUT, "lens_f64.npz"), **out)
 
 
+def pins_golden():
+    """Reference-derived pins for rows whose Python the reference ships: rotation matrices, the
+    sunflower template, the numpy ancestor's Mie angle -> irradiance interpolation and pixel area weights."""
+    import run_simulation_02 as rs
+    import perform_ray_tracing_03 as prt
+    prt.long = int
+    out = {}
+    rng = np.random.default_rng(99)
+    # --- calculate_rotation_matrix (run_simulation_02.py:366-392) ---
+    ang = np.concatenate([np.zeros((1, 3)), rng.uniform(-0.6, 0.6, (7, 3))])
+    out["rot_angles"] = ang
+    out["rot_matrices"] = np.stack([np.asarray(rs.calculate_rotation_matrix(*a)) for a in ang])
+    # --- calculate_sunflower_coordinates (:999-1056): the per-circle phases come from numpy's global generator ---
+    for tag, (dia, npts) in {"a": (600.0, 100.0), "b": (150.0, 25.0), "c": (1000.0, 400.0)}.items():
+        np.random.seed(714)
+        x, y = rs.calculate_sunflower_coordinates(dia, npts)
+        ncirc = int(np.round((dia / 2.0) / np.sqrt(np.pi * (dia / 2.0) ** 2.0 / npts)))
+        np.random.seed(714)
+        out[f"sun_{tag}_phase"] = np.array([float(np.random.rand(1, 1)[0, 0]) for _ in range(ncirc)])
+        out[f"sun_{tag}_args"] = np.array([dia, npts])
+        out[f"sun_{tag}_x"], out[f"sun_{tag}_y"] = np.asarray(x, dtype=np.float64).ravel(), np.asarray(y, dtype=np.float64).ravel()
+    # --- Mie interpolation inside generate_lightfield_angular_data (perform_ray_tracing_03.py:348-469) ---
+    piv = np.load(os.path.join(OUT, "abi_piv.npz"))
+    with open(os.path.join(OUT, "abi_piv.json")) as f:
+        meta = json.load(f)
+    na, nd = meta["scattering"]["num_angles"], meta["scattering"]["num_diameters"]
+    angles = piv["scattering_angle"].astype(np.float64)
+    table = piv["scattering_irradiance"].astype(np.float64).reshape(na, nd)
+    cam_rot = rs.calculate_rotation_matrix(0.05, -0.03, 0.0)
+    sd = dict(scattering_angle=angles, scattering_irradiance=table, inverse_rotation_matrix=cam_rot.transpose(),
+              beam_propogation_vector=np.matrix([[0.0, 1.0, 0.0]]))
+    n_src, L = 24, 64
+    src = dict(x=rng.uniform(-7.5e4, 7.5e4, n_src), y=rng.uniform(-7.5e4, 7.5e4, n_src),
+               z=823668.3478484906 + rng.uniform(-7.5e3, 7.5e3, n_src), radiance=rng.uniform(50, 500, n_src),
+               diameter_index=rng.integers(0, nd, n_src))
+    lens_pitch, image_distance = 13125.0, 123529.41176470589
+    np.random.seed(123)
+    lf = prt.generate_lightfield_angular_data(lens_pitch, image_distance, sd, "mie", src, L, 0, n_src - 1)
+    np.random.seed(123)
+    u = np.empty((n_src, L)); v = np.empty((n_src, L))
+    for n in range(n_src):
+        u[n] = np.random.rand(1, L)[0]
+        v[n] = np.random.rand(1, L)[0]
+    out.update(mie_src_x=src["x"], mie_src_y=src["y"], mie_src_z=src["z"], mie_src_radiance=src["radiance"],
+               mie_src_diameter_index=src["diameter_index"].astype(np.int32), mie_u=u, mie_v=v,
+               mie_radiance=np.asarray(lf["radiance"]).reshape(n_src, L), mie_theta=np.asarray(lf["theta"]).reshape(n_src, L),
+               mie_phi=np.asarray(lf["phi"]).reshape(n_src, L), mie_inverse_rotation=np.asarray(cam_rot.transpose()),
+               mie_lens=np.array([lens_pitch, image_distance]))
+    # --- intersect_sensor_better (:1488-1595): pixel indices + area weights (MATLAB-style +1.5 offset) ---
+    cam = dict(pixel_pitch=17.0, x_pixel_number=1024, y_pixel_number=1024)
+    xs = rng.uniform(-8800.0, 8800.0, 4096)
+    ys = rng.uniform(-8800.0, 8800.0, 4096)
+    ii, jj, w = prt.intersect_sensor_better(cam, xs, ys)
+    out.update(sensor_x=xs, sensor_y=ys, sensor_ii=np.asarray(ii, dtype=np.float64), sensor_jj=np.asarray(jj, dtype=np.float64),
+               sensor_w=np.asarray(w, dtype=np.float64))
+    np.savez_compressed(os.path.join(OUT, "pins.npz"), **out)
+
+
 def main():
     sys.path.insert(0, os.path.join(REF, "python_codes"))
 
@@ -302,6 +383,14 @@ def main():
     save_case("bos_im1", calls[0], post[0], params)
     save_case("bos_im2", calls[1], post[1], params)
     lens_golden()
+    pins_golden()
+    # the sample cases at their REAL size (50 000 particles x 10 000 rays; the full dot grid x 500 rays): source arrays
+    # + scalars only
+    calls, post, params = run_case("piv", lambda p: p["particle_field"].__setitem__("frame_vector", np.array([1])))
+    save_case("piv_full", calls[0], None, params, sources_only=True)
+    calls, post, params = run_case("bos", lambda p: None)
+    save_case("bos_full_im1", calls[0], None, params, sources_only=True)
+    save_case("bos_full_im2", calls[1], None, params, sources_only=True)
     # the one sample volume the reference ships (data, 1 MiB)
     shutil.copyfile(os.path.join(REF, "sample-data", "bos", "sample-density.nrrd"),
                     os.path.join(OUT, "sample-density.nrrd"))

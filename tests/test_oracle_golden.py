@@ -293,3 +293,93 @@ def test_scene_generators_against_numpy(oracle):
     np.testing.assert_allclose(a[..., 3], b[..., 3], rtol=3e-7)         # n-1: exp implementations differ by <= 1 ulp (f64)
     assert np.abs(a[..., :3] - b[..., :3]).max() <= 1e-3 * np.abs(b[..., :3]).max()
     assert vg.info().step_size == vn.info().step_size and list(vg.info().min_bound) == list(vn.info().min_bound)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 2: pins derived from the reference's own Python for rows that have Python behind them (tests/golden/pins.npz,
+# written by make_golden.py from run_simulation_02.py / perform_ray_tracing_03.py).
+# ---------------------------------------------------------------------------------------------------------------
+
+
+@pytest.fixture(scope="module")
+def pins():
+    return np.load(os.path.join(GOLDEN, "pins.npz"))
+
+
+def test_rotation_matrix_matches_reference(pins):
+    """calculate_rotation_matrix (run_simulation_02.py:366-392) for eight angle triples."""
+    from photon_amd.ray_tracing import calculate_rotation_matrix
+    for ang, ref in zip(pins["rot_angles"], pins["rot_matrices"]):
+        assert np.abs(calculate_rotation_matrix(*ang) - ref).max() <= 1e-15
+        assert np.abs(calculate_rotation_matrix(*ang) @ calculate_rotation_matrix(*ang).T - np.eye(3)).max() <= 1e-15
+
+
+def test_concentric_disc_matches_reference_sunflower(pins):
+    """calculate_sunflower_coordinates (run_simulation_02.py:999-1056) with its per-circle random phases captured."""
+    for tag in "abc":
+        dia, npts = pins[f"sun_{tag}_args"]
+        got = scenes.concentric_disc(float(dia), float(npts), pins[f"sun_{tag}_phase"])
+        assert got.shape[0] == pins[f"sun_{tag}_x"].size
+        assert np.abs(got[:, 0] - pins[f"sun_{tag}_x"]).max() <= 1e-9 and np.abs(got[:, 1] - pins[f"sun_{tag}_y"]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("case", ["bos_im1", "bos_full_im1"])
+def test_bos_sources_are_dot_centres_plus_template(oracle, case):
+    """generate_bos_lightfield_data (run_simulation_02.py:1328-1551): the captured source arrays of the sample BOS case
+    (shrunk and at its real size: 1000 dots x 120 points) are exactly dot centre + template point, summed in double and
+    cast to f32 by the marshalling -- what oracle_sources_bos / photon_sources_bos compute (the GPU side of this pin is
+    tests/test_parity_gpu.py::test_bos_sources_on_device_match_reference_capture)."""
+    d = np.load(os.path.join(GOLDEN, f"abi_{case}.npz"))
+    centres = np.stack([d["dot_x"], d["dot_y"]], 1)
+    tmpl = np.stack([d["tmpl_x"], d["tmpl_y"]], 1)
+    got = oracle.sources_bos(centres, tmpl, float(d["src_z"][0]), float(d["src_radiance"][0]))
+    assert got["x"].size == d["src_x"].size == centres.shape[0] * tmpl.shape[0]
+    assert np.array_equal(got["x"], d["src_x"]) and np.array_equal(got["y"], d["src_y"])
+    assert np.array_equal(got["radiance"], d["src_radiance"]) and np.array_equal(got["diameter_index"], d["src_diameter_index"])
+    # the reference's template is its concentric-circle construction
+    dia, npts = d["tmpl_args"]
+    assert tmpl.shape[0] == scenes.concentric_disc(float(dia), float(npts), np.zeros(64)).shape[0]
+
+
+def test_mie_lookup_matches_numpy_ancestor(oracle, pins):
+    """generate_lightfield_angular_data: the CUDA form (parallel_ray_tracing.cu:165-201: acosf of the beam angle, linear
+    interpolation in the [angle][diameter] table) against the reference's f64 numpy ancestor
+    (perform_ray_tracing_03.py:348-469: arccos + scipy interp1d) on the sample Mie table, a rotated camera and 24
+    sources x 64 lens points.  The lens point is the same on both sides: numpy samples r = R sqrt(u), CUDA
+    ratio * pitch * r1 with r1 = sqrt(u) / 2."""
+    call = load_fixture_call("piv")
+    f_number = call.aperture_f_number
+    call.lens_pitch, call.image_distance = (float(v) for v in pins["mie_lens"])
+    call.ray_cone_pitch_ratio = 1.0
+    call.scattering["inverse_rotation_matrix"] = pins["mie_inverse_rotation"].reshape(9)
+    call.scattering["beam_propagation_vector"] = [0.0, 1.0, 0.0]
+    call.src_x, call.src_y, call.src_z = pins["mie_src_x"], pins["mie_src_y"], pins["mie_src_z"]
+    call.src_radiance, call.src_diameter_index = pins["mie_src_radiance"], pins["mie_src_diameter_index"]
+    worst = 0.0
+    for n in range(call.src_x.size):
+        r1 = (np.sqrt(pins["mie_u"][n]) / 2.0).astype(np.float32)
+        pos, d, rad = oracle.generate_rays(call, n, r1, pins["mie_v"][n].astype(np.float32))
+        want = pins["mie_radiance"][n] / (f_number * f_number)           # .cu:233: radiance = 1/f#^2 * irradiance
+        rel = np.abs(rad - want) / np.abs(want)
+        worst = max(worst, float(rel.max()))
+        # direction: tan(theta) of the CUDA ray == the ancestor's small-angle theta (it stores the slope)
+        assert np.abs(d[:, 0] / -d[:, 2] - pins["mie_theta"][n]).max() <= 2e-7
+        assert np.abs(d[:, 1] / -d[:, 2] - pins["mie_phi"][n]).max() <= 2e-7
+    assert worst <= 2e-4, worst        # f32 angle (ulp 1.2e-7 rad on ~1.5 rad) x table slope; measured 2.8e-5
+
+
+def test_pixel_area_weights_match_numpy_ancestor(oracle, pins):
+    """intersect_sensor (parallel_ray_tracing.cu:1803-1880) against intersect_sensor_better
+    (perform_ray_tracing_03.py:1488-1595).  The ancestor works in MATLAB pixel units: d = (x - x1)/pitch + 1.5, so its
+    pixel grid sits half a pixel and one index off the CUDA one -- evaluated at x + pitch/2 the CUDA
+    function must give the same four weights and indices exactly one lower."""
+    cam = scenes.sample_camera(False)
+    pitch = cam["pixel_pitch"]
+    ii, jj, w, inside = oracle.pixel_taps(cam, pins["sensor_x"] + pitch / 2.0, pins["sensor_y"] + pitch / 2.0)
+    ref_w = pins["sensor_w"]
+    ok = inside & np.isfinite(ref_w).all(1)
+    assert ok.sum() > 4000
+    assert np.array_equal(ii[ok] + 1, pins["sensor_ii"][ok].astype(np.int32))
+    assert np.array_equal(jj[ok] + 1, pins["sensor_jj"][ok].astype(np.int32))
+    assert np.abs(w[ok] - ref_w[ok]).max() <= 2e-4          # f32 pixel coordinate (ulp 6e-5 at 1000 px) vs f64
+    assert np.abs(w[ok].sum(1) - 1.0).max() <= 1e-12

@@ -580,6 +580,23 @@ def test_ray_order_does_not_change_the_image(photon, oracle, small_volume_file, 
     scene.free(); vol.free()
 
 
+@pytest.mark.parametrize("case", ["bos_im1", "bos_full_im1"])
+def test_bos_sources_on_device_match_reference_capture(photon, golden_dir, case):
+    """photon_sources_bos fed with the reference generator's own dot centres and point template
+    (generate_bos_lightfield_data / calculate_sunflower_coordinates, run_simulation_02.py:1328-1551, 999-1056, captured
+    by make_golden.py) reproduces, bit for bit, the source arrays the reference's marshalling handed to
+    start_ray_tracing for the sample BOS case (shrunk, and at its real size of 120 000 sources)."""
+    d = np.load(os.path.join(golden_dir, f"abi_{case}.npz"))
+    src = photon.sources_bos(np.stack([d["dot_x"], d["dot_y"]], 1), np.stack([d["tmpl_x"], d["tmpl_y"]], 1),
+                             float(d["src_z"][0]), float(d["src_radiance"][0]))
+    got = src.download()
+    src.free()
+    assert got["x"].size == d["src_x"].size
+    for key, ref in (("x", "src_x"), ("y", "src_y"), ("z", "src_z"), ("radiance", "src_radiance"),
+                     ("diameter_index", "src_diameter_index")):
+        assert np.array_equal(got[key], d[ref]), key
+
+
 def _centroid(img):
     yy, xx = np.mgrid[0:img.shape[0], 0:img.shape[1]]
     w = img.astype(np.float64)
