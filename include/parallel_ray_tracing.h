@@ -127,17 +127,19 @@ typedef struct camera_design_t {
  * Environment knobs (the ABI has no room for new arguments):
  *   PHOTON_INTERP=linear|cubic   volume sampler (default linear = the reference's
  *                                hard-coded interpolation_scheme 1, .cu:3330)
- *   PHOTON_TEX_WEIGHTS=exact|fixed8   trilinear weights: exact f32 (default) or 8 fractional bits like
- *                                the texture unit the reference runs on (photon_volume_set_weight_bits)
+ *   PHOTON_TEX_WEIGHTS=fixed8|exact   trilinear weights: 8 fractional bits like the texture unit the reference's
+ *                                tex3D() runs on (default) or exact f32 (photon_volume_set_weight_bits)
  *   PHOTON_VERBOSE=1             progress / timing on stdout
  *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
  *                                reference seeds cuRAND with time(NULL); default 0x5eed)
  *   PHOTON_ELEMENT_TRAIN=reference|sequential   element-group walk (photon_scene_set_element_train)
  *   PHOTON_SKIP_DOOMED=0|1       1 (default): rays that provably die on the first aperture are not marched
  *   PHOTON_RAY_ORDER=source|lens|auto           lane order of a launch (photon_scene_set_ray_order)
- *   PHOTON_DEVICES=all|0,1,..    shard the sources of one call over several GPUs (one host thread
- *                                and one private image per device, summed at the end); default:
- *                                the calling thread's current device
+ *   PHOTON_DEVICES=all|0,1,..    shard the sources of one call over several GPUs: one host thread per
+ *                                device uploads only its block of the sources, the NRRD is parsed once, the
+ *                                private f64 accumulators are summed on the first device (peer copies +
+ *                                a kernel) and folded into image_array once; default: the calling
+ *                                thread's current device (which is restored on return in every case)
  */
 void start_ray_tracing(float lens_pitch, float image_distance,
                        scattering_data_t *scattering_data_p, char *scattering_type_str,
@@ -203,11 +205,12 @@ int photon_volume_from_density(const float *rho, int nx, int ny, int nz,
                                const double spacing[3], const double origin[3],
                                int interpolation, photon_volume_t **out);
 int photon_volume_info(const photon_volume_t *vol, photon_volume_info_t *info);
-/* Trilinear interpolation weights: bits = 0 (default) exact f32; bits = 8 rounds them to 8 fractional bits, the
- * 9-bit fixed-point weights CUDA's linear texture filter uses (CUDA C Programming Guide, "Linear Filtering") --
- * i.e. what the reference's tex3D() fetches (trace_rays_through_density_gradients.h:1052 ...) compute with on
- * NVIDIA hardware.  Takes effect for every later sample / trace of this volume; the tricubic sampler (always
- * the exact 64-tap sum) is unaffected.  start_ray_tracing reads PHOTON_TEX_WEIGHTS=exact|fixed8. */
+/* Trilinear interpolation weights: bits = 8 (default) rounds them to 8 fractional bits, the 9-bit fixed-point
+ * weights CUDA's linear texture filter uses (CUDA C Programming Guide, "Linear Filtering") -- i.e. what the
+ * reference's tex3D() fetches (trace_rays_through_density_gradients.h:1052 ...) compute with on NVIDIA
+ * hardware; bits = 0 keeps them exact f32.  Takes effect for every later sample / trace of this volume; the
+ * tricubic sampler (always the exact 64-tap sum) is unaffected.  start_ray_tracing reads
+ * PHOTON_TEX_WEIGHTS=fixed8|exact. */
 int photon_volume_set_weight_bits(photon_volume_t *vol, int bits);
 /* Copy the float4 texels (grad x,y,z, n-1) -- or the B-spline coefficients when
  * interpolation==2 and coefficients!=0 -- back to the host: f32[nz*ny*nx*4]. */
@@ -344,6 +347,23 @@ int photon_density_gaussian_write_nrrd(const char *path, int nx, int ny, int nz,
 
 /* Library / build identification string (static storage). */
 const char *photon_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Section 4: sensor post-processing on the device (the step right after the
+ * hot path).  Replaces perform_ray_tracing_03.py:2190-2259 (noise -> clip -> 10^(gain/20) ->
+ * normalise to the brightest pixel -> round to pixel_bit_depth -> stretch to 16 bit -> uint16 ->
+ * optional centre crop), in f32 in numpy's evaluation order, so that the raw image stays in HBM and
+ * only the uint16 picture crosses the bus.
+ *   d_image   device f32[height*width], row-major; rewritten only when image_noise > 0 (the reference adds the
+ *             noise to I_raw itself, :2196-2206; here N(0, 100 image_noise) from Philox(noise_seed, pixel))
+ *   crop_rows / crop_cols   0 = no crop; otherwise the reference's window rows [H/2 - r/2, H/2 + r/2 - 1) (integer
+ *             division; one row / column fewer than asked, as its slice has it) -- *out_rows / *out_cols receive
+ *             the size of the result (may be NULL)
+ *   d_out     device uint16[out_rows*out_cols]
+ * Synchronises `stream` before returning. */
+int photon_postprocess_u16(float *d_image, int width, int height, float pixel_gain, int pixel_bit_depth,
+                           int intensity_rescaling, float image_noise, uint64_t noise_seed, int crop_rows, int crop_cols,
+                           uint16_t *d_out, int *out_rows, int *out_cols, void *stream);
 
 #ifdef __cplusplus
 }

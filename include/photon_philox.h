@@ -56,6 +56,6 @@ PHOTON_HD void photon_normal2(uint64_t seed, uint64_t ray_id, uint32_t draw, uin
     *n1 = (float)(rad * s);
 }
 
-enum { PHOTON_STREAM_POS_NOISE = 1, PHOTON_STREAM_NGRAD_NOISE = 2, PHOTON_STREAM_SCENE = 3 };
+enum { PHOTON_STREAM_POS_NOISE = 1, PHOTON_STREAM_NGRAD_NOISE = 2, PHOTON_STREAM_SCENE = 3, PHOTON_STREAM_IMAGE_NOISE = 4 };
 
 #endif /* PHOTON_PHILOX_H_ */

@@ -25,6 +25,8 @@ DECLARED_SYMBOLS = (
     # section 3: scene generation on the device
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
     "photon_scene_create_from_sources", "photon_volume_gaussian", "photon_density_gaussian_write_nrrd",
+    # section 4: sensor post-processing on the device
+    "photon_postprocess_u16",
 )
 
 
@@ -116,6 +118,10 @@ class PhotonLibrary:
                                              ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
                                              ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
 
+        L.photon_postprocess_u16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_float, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+
     # ---- helpers --------------------------------------------------------------------------
     @staticmethod
     def _check(rc: int, what: str):
@@ -141,6 +147,19 @@ class PhotonLibrary:
             image = call.new_image()
         call.invoke(self.start_ray_tracing, image)
         return image
+
+    # ---- sensor post-processing on the device (perform_ray_tracing_03.py:2190-2259) -----------------
+    def postprocess_u16(self, d_image_ptr: int, width: int, height: int, d_out_ptr: int, pixel_gain: float,
+                        pixel_bit_depth: int, intensity_rescaling: bool = True, image_noise: float = 0.0, noise_seed: int = 0,
+                        crop_rows: int = 0, crop_cols: int = 0, stream: int = 0):
+        """Device f32 image -> device uint16 picture (raw pointers); returns (rows, cols) of the result."""
+        r, c = ctypes.c_int(0), ctypes.c_int(0)
+        rc = self.lib.photon_postprocess_u16(ctypes.c_void_p(int(d_image_ptr)), int(width), int(height), float(pixel_gain),
+                                             int(pixel_bit_depth), int(bool(intensity_rescaling)), float(image_noise),
+                                             int(noise_seed), int(crop_rows), int(crop_cols), ctypes.c_void_p(int(d_out_ptr)),
+                                             ctypes.byref(r), ctypes.byref(c), ctypes.c_void_p(int(stream)) if stream else None)
+        self._check(rc, "photon_postprocess_u16")
+        return r.value, c.value
 
     # ---- volumes ------------------------------------------------------------------------------
     def volume_load_nrrd(self, path: str, interpolation: int = 1) -> "Volume":

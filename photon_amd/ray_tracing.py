@@ -398,11 +398,20 @@ def single_lens_camera(focal_length: float, aperture_f_number: float, object_dis
 # ----------------------------------------------------------------------------------------------
 
 
+def crop_window(n_rows: int, n_cols: int, r_crop: int, c_crop: int):
+    """The reference's centre crop (perform_ray_tracing_03.py:2250-2259): rows [nr/2 - r/2, nr/2 + r/2 - 1) with
+    integer division -- one row and one column FEWER than asked for, as its slice has it."""
+    r0, c0 = n_rows // 2 - r_crop // 2, n_cols // 2 - c_crop // 2
+    return slice(r0, n_rows // 2 + r_crop // 2 - 1), slice(c0, n_cols // 2 + c_crop // 2 - 1)
+
+
 def postprocess_image(I_raw: np.ndarray, pixel_gain: float, pixel_bit_depth: int,
                       intensity_rescaling: bool = True, image_noise: float = 0.0,
                       rng: Optional[np.random.Generator] = None) -> np.ndarray:
     """Raw float image -> uint16 sensor image: (noise) -> clip<0 -> 10^(gain/20) ->
-    normalise to the brightest pixel -> round to bit depth -> stretch to 16 bit."""
+    normalise to the brightest pixel -> round to bit depth -> stretch to 16 bit.  Host (numpy) form, pinned pixel
+    for pixel against the reference's output; the device form is photon_postprocess_u16
+    (PhotonLibrary.postprocess_u16), pinned against the same fixtures."""
     I = np.array(I_raw, dtype=np.float32, copy=True)
     if image_noise > 0.0:
         rng = rng or np.random.default_rng()

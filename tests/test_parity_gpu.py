@@ -531,12 +531,17 @@ def test_texture_unit_weights(photon, oracle, small_volume_file, monkeypatch):
     # through the ABI
     call = scenes.bos_scene(n_dots=8, points_per_dot=20, rays_per_source=100, density_grad_filename=small_volume_file)
     monkeypatch.setenv("PHOTON_INTERP", "linear")
+    monkeypatch.setenv("PHOTON_TEX_WEIGHTS", "exact")
     exact = photon.render(call)
+    ref_exact, _ = oracle.render(call, interpolation=1, tex_frac_bits=0)
+    assert rel_l2(exact, ref_exact) <= IMAGE_TOL, rel_l2(exact, ref_exact)
     monkeypatch.setenv("PHOTON_TEX_WEIGHTS", "fixed8")
     fixed = photon.render(call)
     ref, _ = oracle.render(call, interpolation=1, tex_frac_bits=8)
     assert rel_l2(fixed, ref) <= IMAGE_TOL, rel_l2(fixed, ref)
     assert not np.array_equal(fixed, exact)                     # (a smooth field: the two differ by ~1e-5 rel. L2)
+    monkeypatch.delenv("PHOTON_TEX_WEIGHTS")                    # the default is the texture unit's arithmetic
+    assert np.array_equal(photon.render(call), fixed)
 
 
 def test_ray_order_does_not_change_the_image(photon, oracle, small_volume_file, monkeypatch):
@@ -884,3 +889,49 @@ def test_c4_one_gpu_share_properties(photon, workdir, monkeypatch):
         vol.free()
     assert 0 < rel_l2(images[1], images[2]) < 2e-2
     scene.free()
+
+
+@pytest.mark.parametrize("case", ["piv", "bos_im1", "bos_im2"])
+def test_postprocess_on_device_matches_reference(photon, golden_dir, case):
+    """photon_postprocess_u16 (SURVEY 8f rank 1 behind the C-ABI): the uint16 picture the reference's own
+    post-processing (perform_ray_tracing_03.py:2190-2247) made of a synthetic raw image, reproduced on the device pixel
+    for pixel; then the centre crop (:2250-2259) and the no-rescaling branch against the numpy mirror."""
+    import json
+    import torch
+    from photon_amd.ray_tracing import crop_window, postprocess_image
+    a = np.load(os.path.join(golden_dir, f"postprocess_{case}.npz"))
+    with open(os.path.join(golden_dir, f"abi_{case}.json")) as f:
+        pp = json.load(f)["postprocess"]
+    H, W = (int(v) for v in a["shape"])
+    raw = np.zeros(H * W, np.float32)
+    raw[a["raw_index"]] = a["raw_value"]
+    raw[11] = np.nan                                                    # non-finite pixels are zeroed (:2228)
+    ref = np.zeros(H * W, np.uint16)
+    ref[a["out_u16_index"]] = a["out_u16_value"]
+    d_raw = torch.from_numpy(raw).cuda()
+    d_out = torch.zeros(H * W, dtype=torch.int16, device="cuda")
+    rows, cols = photon.postprocess_u16(d_raw.data_ptr(), W, H, d_out.data_ptr(), pp["pixel_gain"], int(pp["pixel_bit_depth"]),
+                                        pp["intensity_rescaling"])
+    assert (rows, cols) == (H, W)
+    got = d_out.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(d_raw.cpu().numpy(), raw, equal_nan=True)     # without noise the raw image is only read
+    # crop: the reference's window, one row / column short of what was asked
+    rows, cols = photon.postprocess_u16(d_raw.data_ptr(), W, H, d_out.data_ptr(), pp["pixel_gain"], int(pp["pixel_bit_depth"]),
+                                        True, crop_rows=300, crop_cols=200)
+    rs, cs = crop_window(H, W, 300, 200)
+    assert (rows, cols) == (299, 199) == (rs.stop - rs.start, cs.stop - cs.start)
+    want = postprocess_image(np.nan_to_num(raw, nan=0.0).reshape(H, W), pp["pixel_gain"], int(pp["pixel_bit_depth"]))[rs, cs]
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint16)[:rows * cols].reshape(rows, cols), want)
+    # intensity_rescaling off: clip and convert only
+    photon.postprocess_u16(d_raw.data_ptr(), W, H, d_out.data_ptr(), pp["pixel_gain"], int(pp["pixel_bit_depth"]), False)
+    want = postprocess_image(np.nan_to_num(raw, nan=0.0).reshape(H, W), pp["pixel_gain"], int(pp["pixel_bit_depth"]), False)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint16).reshape(H, W), want)
+    # seeded sensor noise: rewrites the raw image like the reference does, reproducibly
+    photon.postprocess_u16(d_raw.data_ptr(), W, H, d_out.data_ptr(), pp["pixel_gain"], int(pp["pixel_bit_depth"]), True,
+                           image_noise=0.05, noise_seed=3)
+    noisy = d_raw.cpu().numpy()
+    delta = (noisy - raw)[np.isfinite(raw)]
+    assert abs(float(delta.std()) - 5.0) < 0.05 and abs(float(delta.mean())) < 0.05
+    with pytest.raises(Exception):
+        photon.postprocess_u16(d_raw.data_ptr(), W, H, d_out.data_ptr(), 0.0, 10, True, crop_rows=4 * H, crop_cols=10)
