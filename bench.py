@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--interp", choices=["cubic", "linear"], default="cubic")
+    ap.add_argument("--algorithm", type=int, choices=[1, 2], default=2, help="1 Euler, 2 RK4 (the headline)")
     ap.add_argument("--volume", type=int, default=256, help="grid points per axis of the density volume")
     ap.add_argument("--dots", type=int, default=200, help="BOS dots of the job (strong) / per GPU (weak); x100 sources x500 rays")
     ap.add_argument("--rays-per-source", type=int, default=500)
@@ -166,7 +167,7 @@ def measure_hbm_traffic(args, kernel_tag: str):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-sample-rays", "0", "--no-traffic",
-                   "--interp", args.interp, "--volume", str(args.volume), "--dots", str(args.dots),
+                   "--interp", args.interp, "--algorithm", str(args.algorithm), "--volume", str(args.volume), "--dots", str(args.dots),
                    "--rays-per-source", str(args.rays_per_source)]
             env = dict(os.environ, TMPDIR="/tmp", PHOTON_BENCH_CHILD="1")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
@@ -290,7 +291,7 @@ def main():
 
     def step(want_stats):
         image.zero_()
-        st = scene.trace(image.data_ptr(), volume, 2, src_begin, src_end, stream=stream, want_stats=want_stats)
+        st = scene.trace(image.data_ptr(), volume, args.algorithm, src_begin, src_end, stream=stream, want_stats=want_stats)
         reduce_image(image, 0)
         return st
 
@@ -326,7 +327,8 @@ def main():
     # ---- roofline of the dominant kernel (march_kernel<rk4, interp>), this rank's launch --------
     s_bar = iters / max(rays_rank, 1)
     a_bar = taps / max(rays_rank, 1)
-    bytes_per_ray = s_bar * 3 * TEXELS_PER_SAMPLE[interp] * 16 + a_bar * 8 + 40
+    samples_per_iter = 3 if args.algorithm == 2 else 1
+    bytes_per_ray = s_bar * samples_per_iter * TEXELS_PER_SAMPLE[interp] * 16 + a_bar * 8 + 40
     march_ms_avg = march_ms / args.steps
     achieved = rays_rank * bytes_per_ray / (march_ms_avg * 1e-3) * 1e-9 if march_ms_avg > 0 else 0.0
     flops_per_sample = {"linear": 100.0, "cubic": 570.0}[args.interp]
@@ -340,7 +342,7 @@ def main():
     # texels per sample) neither pipe is near its peak: it is instruction-issue bound.
     roofline = {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / LDS_PEAK_GBS, 4), "traffic": None,
-                "kernel": f"march_kernel<rk4,{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
+                "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
                 "sensor_taps_per_ray": round(a_bar, 2), "rays_per_launch": rays_rank,
                 "valu_f32": {"achieved": round(tflops, 2), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -368,7 +370,8 @@ def main():
                 roofline["hbm"]["traffic_gbs"] = round(gbs, 1)
                 roofline["hbm"]["frac"] = round(gbs / HBM_PEAK_GBS, 4)
         desc = (f"C3: BOS, {total_rays} rays ({call.num_sources} sources x {args.rays_per_source}"
-                f"{' per GPU' if not strong and world > 1 else ''}), {args.volume}^3 volume, RK4, {args.interp} sampler, "
+                f"{' per GPU' if not strong and world > 1 else ''}), {args.volume}^3 volume, "
+                f"{'RK4' if args.algorithm == 2 else 'Euler'}, {args.interp} sampler, "
                 f"erf splat D=3, 1024^2 sensor")
         out = {
             "metric": "Mrays/sec, 1e7-ray 256^3 BOS render", "value": round(value, 3), "unit": "Mrays/s",

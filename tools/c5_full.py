@@ -5,7 +5,7 @@ from photon_amd import scenes
 from photon_amd.library import PhotonLibrary
 lib = PhotonLibrary()
 work = os.path.join(tempfile.gettempdir(), "photon_bench"); os.makedirs(work, exist_ok=True)
-t0 = time.perf_counter(); call = scenes.config("C5", work, scale=1.0); t1 = time.perf_counter()
+t0 = time.perf_counter(); call = scenes.config("C5", work, scale=float(sys.argv[1]) if len(sys.argv) > 1 else 1.0); t1 = time.perf_counter()
 scene = lib.scene_create(call)
 vol = lib.volume_load_nrrd(call.density_grad_filename, 2)
 H, W = call.image_shape
