@@ -379,15 +379,7 @@ __device__ __forceinline__ Ray optical_system(const SceneDev &sc, Ray ray) {
 // reference's atomicAdd(float) in arbitrary order loses up to N*2^-25 relative on a pixel that
 // receives N near-identical increments (BOS dots: N ~ 1e4), far above the 1e-5 parity bar.
 //
-// The 64 rays of a wave come from one or two neighbouring sources, so their spots cover the same
-// few pixels: issued per lane, the ~16 atomics of each ray all collide (measured: the sensor stage
-// 82 % issue-stalled on atomics).  erf_splat_wave therefore works per 8x8 pixel TILE: every lane
-// evaluates its contribution to the tile's 64 pixels (the erf differences depend on the column
-// resp. row only: 16 + 16 erf per tile), a 6-stage butterfly reduce-scatters the 64 x 64 values
-// across the wave so that each lane ends up owning ONE pixel's sum, and the wave issues a single
-// atomic instruction with 64 distinct addresses.  Waves whose spots spread over more than
-// kSplatTiles tiles fall back to per-lane atomics.  Values are the reference's, term for term; only
-// the (f64) summation order differs.
+// The per-lane form below (erf_splat_lane) is the fallback; the wave-cooperative form follows it.
 // ---------------------------------------------------------------------------------------------
 struct SplatReq {
     bool valid;                 // this lane has a ray to splat
@@ -447,75 +439,113 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
-// 32 values per lane -> each lane keeps the sum over the wave of value (lane >> 1) & 31
-// (lanes 2p and 2p+1 both end with pixel p's total).
-__device__ __forceinline__ double reduce_scatter32(const double (&a)[32], int lane) {
-    double b[16], c[8], d[4], e[2];
-    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4, h1 = lane & 2;
-#pragma unroll
-    for (int j = 0; j < 16; j++) b[j] = (h5 ? a[16 + j] : a[j]) + __shfl_xor(h5 ? a[j] : a[16 + j], 32, 64);
-#pragma unroll
-    for (int j = 0; j < 8; j++) c[j] = (h4 ? b[8 + j] : b[j]) + __shfl_xor(h4 ? b[j] : b[8 + j], 16, 64);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = (h3 ? c[4 + j] : c[j]) + __shfl_xor(h3 ? c[j] : c[4 + j], 8, 64);
-#pragma unroll
-    for (int j = 0; j < 2; j++) e[j] = (h2 ? d[2 + j] : d[j]) + __shfl_xor(h2 ? d[j] : d[2 + j], 4, 64);
-    double r = (h1 ? e[1] : e[0]) + __shfl_xor(h1 ? e[0] : e[1], 2, 64);
-    r += __shfl_xor(r, 1, 64);
-    return r;
-}
-
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative splats.  The 64 rays of a wave land on a handful of neighbouring pixels (BOS: the narrow cone of
+// one source; PIV without a volume: the rays of one particle converge on its image; lens-major PIV: 64 neighbouring
+// particles), so issued per lane their atomics all collide.  Instead the wave TRANSPOSES the work through its own LDS
+// area: every lane (ray) parks what it contributes -- for the erf splat its separable per-column / per-row factors,
+// 16 erf evaluations, for the 4-pixel splat its four increments -- then every lane becomes a PIXEL of an 8x8 tile of
+// the wave's window, walks the parked rays (broadcast LDS reads), sums what they add to its pixel in f64, and the wave
+// issues ONE atomic instruction with 64 distinct addresses per tile.  Values are the reference's, term for term; only
+// the (f64) summation order differs.  Waves whose window needs more than kSplatTiles tiles, or whose spots are too
+// large for the parked layout, fall back to per-lane atomics.
+// ---------------------------------------------------------------------------------------------
 constexpr int kSplatTiles = 6;
+constexpr int kSplatSlots = 7;              // columns / rows of one ray's window the parked layout carries (D = 3: 6 or 7)
 
-// Must be called by all 64 lanes of the wave.  Returns this lane's number of rendered pixels.
-__device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const SplatReq &q) {
+struct SplatLds {                           // one wave's area: 8.5 KiB
+    float4 head[64];                        // X, Y, rfD, bits(c0)
+    int2 head2[64];                         // r0, nw | nh << 8
+    double f[64][2 * kSplatSlots];          // scale * d_erf(column c0 + j), j < 7 | d_erf(row r0 + j)
+};
+
+// Must be called by all 64 lanes of the wave.  Returns this lane's share of the number of rendered pixels (the wave's
+// total is what the callers accumulate).
+__device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const SplatReq &q, SplatLds &lds) {
     const unsigned long long any = __ballot(q.valid);
     if (any == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int nw = q.c1 - q.c0 + 1, nh = q.r1 - q.r0 + 1;
     const int big = 0x3fffffff;
     const int cmin = wave_min_i(q.valid ? q.c0 : big), cmax = wave_max_i(q.valid ? q.c1 : -big);
     const int rmin = wave_min_i(q.valid ? q.r0 : big), rmax = wave_max_i(q.valid ? q.r1 : -big);
     const int tiles_x = (cmax - cmin) / 8 + 1, tiles_y = (rmax - rmin) / 8 + 1;
-    if (tiles_x * tiles_y > kSplatTiles) return q.valid ? erf_splat_lane(image, W, H, q) : 0;    // wave-uniform branch
-    const int lane = threadIdx.x & 63;
+    const bool fits = !q.valid || (nw <= kSplatSlots && nh <= kSplatSlots);
+    if (__ballot(!fits) != 0 || tiles_x * tiles_y > kSplatTiles)        // wave-uniform branch
+        return q.valid ? erf_splat_lane(image, W, H, q) : 0;
     const float sqrt8 = sqrtf(8.0f);
+    // ---- park this ray's factors.  The reference evaluates erf at both edges of every pixel; neighbouring pixels share
+    // an edge, and (idx - X) +- 0.5 is the same double from either side whenever the f32 difference idx - X is exact --
+    // it is for X >= 8 (|idx - X| < 8 then needs no more bits than X has).  Rays nearer the image's first columns /
+    // rows evaluate both edges like the reference does.
+    if (q.valid) {
+        const bool exact_x = q.X >= 8.0f, exact_y = q.Y >= 8.0f;
+        double *fx = lds.f[lane], *fy = lds.f[lane] + kSplatSlots;
+        if (exact_x) {
+            double lo = erf(sqrt8 * (q.c0 - q.X - 0.5) / q.D);
+#pragma unroll
+            for (int j = 0; j < kSplatSlots; j++) {
+                if (j < nw) {
+                    const double hi = erf(sqrt8 * (q.c0 + j - q.X + 0.5) / q.D);
+                    fx[j] = q.scale * (lo - hi);
+                    lo = hi;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSplatSlots; j++)
+                if (j < nw) fx[j] = q.scale * erf_edge_diff(sqrt8, q.c0 + j, q.X, q.D);
+        }
+        if (exact_y) {
+            double lo = erf(sqrt8 * (q.r0 - q.Y - 0.5) / q.D);
+#pragma unroll
+            for (int j = 0; j < kSplatSlots; j++) {
+                if (j < nh) {
+                    const double hi = erf(sqrt8 * (q.r0 + j - q.Y + 0.5) / q.D);
+                    fy[j] = lo - hi;
+                    lo = hi;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSplatSlots; j++)
+                if (j < nh) fy[j] = erf_edge_diff(sqrt8, q.r0 + j, q.Y, q.D);
+        }
+        lds.head[lane] = make_float4(q.X, q.Y, q.rfD, __int_as_float(q.c0));
+        lds.head2[lane] = make_int2(q.r0, nw | (nh << 8));
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- every lane is now a pixel of an 8x8 tile of the wave's window
     int taps = 0;
     for (int ty = 0; ty < tiles_y; ty++)
         for (int tx = 0; tx < tiles_x; tx++) {
             const int tc = cmin + 8 * tx, tr = rmin + 8 * ty;           // tile origin (wave-uniform)
-            // does this lane's window touch the tile at all?
             const bool touch = q.valid && q.c0 <= tc + 7 && q.c1 >= tc && q.r0 <= tr + 7 && q.r1 >= tr;
-            if (__ballot(touch) == 0) continue;                         // wave-uniform
-            double sx[8], ey[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                sx[i] = touch ? q.scale * erf_edge_diff(sqrt8, tc + i, q.X, q.D) : 0.0;
-                ey[i] = touch ? erf_edge_diff(sqrt8, tr + i, q.Y, q.D) : 0.0;
-            }
-            double mine[2];
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                double a[32];
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++)
-#pragma unroll
-                    for (int cc = 0; cc < 8; cc++) {
-                        const int col = tc + cc, row = tr + 4 * half + rr;
-                        const float rad = sqrtf((col - q.X) * (col - q.X) + (row - q.Y) * (row - q.Y));
-                        const bool render = touch && col >= q.c0 && col <= q.c1 && row >= q.r0 && row <= q.r1 &&
-                                            col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1 && rad <= q.rfD;
-                        const float inc = (float)(sx[cc] * ey[4 * half + rr]);
-                        a[rr * 8 + cc] = render ? (double)inc : 0.0;
-                        taps += render ? 1 : 0;
+            unsigned long long rays = __ballot(touch);                  // rays whose window meets this tile
+            if (rays == 0) continue;
+            const int col = tc + (lane & 7), row = tr + (lane >> 3);
+            const bool in_image = col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1;
+            double sum = 0.0;
+            while (rays != 0) {                                         // wave-uniform loop over the parked rays
+                const int r = __ffsll((long long)rays) - 1;
+                rays &= rays - 1;
+                const float4 h = lds.head[r];                           // broadcast reads
+                const int2 h2 = lds.head2[r];
+                const int jx = col - __float_as_int(h.w), jy = row - h2.x;
+                if (in_image && (unsigned)jx < (unsigned)(h2.y & 0xff) && (unsigned)jy < (unsigned)(h2.y >> 8)) {
+                    const float rad = sqrtf((col - h.x) * (col - h.x) + (row - h.y) * (row - h.y));
+                    if (rad <= h.z) {
+                        const float inc = (float)(lds.f[r][jx] * lds.f[r][kSplatSlots + jy]);
+                        sum += (double)inc;
+                        taps++;
                     }
-                mine[half] = reduce_scatter32(a, lane);
+                }
             }
-            // lanes 2p / 2p+1 own pixel p of the upper / lower half-tile: 64 distinct addresses
-            const int p = lane >> 1, half = lane & 1;
-            const int col = tc + (p & 7), row = tr + 4 * half + (p >> 3);
-            const double v = half ? mine[1] : mine[0];
-            if (v != 0.0 && col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1)
-                atomicAdd(&image[(size_t)row * W + col], v);
+            if (sum != 0.0) atomicAdd(&image[(size_t)row * W + col], sum);
         }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                                    // the area may be re-parked by the caller's next use
     return taps;
 }
 
@@ -572,9 +602,16 @@ __device__ __forceinline__ f3 apparent_image(const Ray &ray, const camera_design
     return hit;
 }
 
-// intersect_sensor + 4-pixel area-weighted splat (.cu:1735-1895, :2199-2234)
-__device__ __forceinline__ f3 sensor_bilinear(double *image, const Ray &ray, const camera_design_t &cam, int &taps,
-                                              const NoiseDev &nz, unsigned long long ray_id) {
+// intersect_sensor + 4-pixel area-weighted splat (.cu:1735-1895, :2199-2234).  The increments are handed back in
+// `req` (bilinear_splat_wave adds them to the image); returns the sensor hit (NaN = outside the sensor, nothing to add).
+struct TapReq {
+    bool valid;
+    int ii_ul, jj_ul;           // upper-left pixel of the four (row, column)
+    float inc[4];               // the reference's f32 increments for (ii, jj), (ii, jj+1), (ii+1, jj), (ii+1, jj+1)
+};
+
+__device__ __forceinline__ f3 sensor_bilinear(const Ray &ray, const camera_design_t &cam, TapReq &req, const NoiseDev &nz,
+                                              unsigned long long ray_id) {
     f3 hit = sensor_hit(ray, 0.0f, 0.0f, 1.0f, -cam.z_sensor, ray.dir);
     add_position_noise(hit, cam, nz, ray_id);
     const f3 dir = ray.dir;
@@ -591,20 +628,78 @@ __device__ __forceinline__ f3 sensor_bilinear(double *image, const Ray &ray, con
     const double d_jj_ul = ceilf(d_x_lower) - d_x_lower;
     const double w[4] = {d_ii_ul * d_jj_ul, d_ii_ul * (1 - d_jj_ul), (1 - d_ii_ul) * d_jj_ul,
                          (1 - d_ii_ul) * (1 - d_jj_ul)};
-    const int ii_ul = (int)(ceilf(d_y_lower) - 1), jj_ul = (int)(ceilf(d_x_lower) - 1);
-    const int ii[4] = {ii_ul, ii_ul, ii_ul + 1, ii_ul + 1};
-    const int jj[4] = {jj_ul, jj_ul + 1, jj_ul, jj_ul + 1};
-    const int W = cam.x_pixel_number, H = cam.y_pixel_number;
+    req.valid = true;
+    req.ii_ul = (int)(ceilf(d_y_lower) - 1);
+    req.jj_ul = (int)(ceilf(d_x_lower) - 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) req.inc[k] = (float)(w[k] * ray.radiance * cos4);
+    return hit;
+}
+
+// which of a hit's four taps the reference actually adds (.cu:2223-2233): pixel inside the sensor, and its index
+// (ii-1)*W + jj-1 not before the image (the reference writes there; skipped here and in the oracle)
+__device__ __forceinline__ bool tap_lands(int ii, int jj, int W, int H) {
+    return !(ii < 0 || ii >= H || jj < 0 || jj >= W) && ((long)(ii - 1) * W + jj - 1) >= 0;
+}
+
+// per-lane form (fallback): one atomic per tap
+__device__ __forceinline__ int bilinear_splat_lane(double *image, int W, int H, const TapReq &q) {
+    int taps = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (ii[k] < 0 || ii[k] >= H || jj[k] < 0 || jj[k] >= W) continue;
-        const long idx = (long)(ii[k] - 1) * W + jj[k] - 1;        // the reference's index (.cu:2228)
-        if (idx < 0) continue;                                      // would write before the image
-        const double inc = w[k] * ray.radiance * cos4;
-        atomicAdd(&image[idx], (double)(float)inc);
+        const int ii = q.ii_ul + (k >> 1), jj = q.jj_ul + (k & 1);
+        if (!tap_lands(ii, jj, W, H)) continue;
+        atomicAdd(&image[(long)(ii - 1) * W + jj - 1], (double)q.inc[k]);
         taps++;
     }
-    return hit;
+    return taps;
+}
+
+// Wave-cooperative form (see erf_splat_wave): rays park (ii_ul, jj_ul, four increments), lanes become the pixels of
+// 8x8 tiles of the wave's window and sum what the parked rays add to them; one atomic per pixel per wave.  Must be
+// called by all 64 lanes.
+__device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, const TapReq &q, SplatLds &lds) {
+    const unsigned long long any = __ballot(q.valid);
+    if (any == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int big = 0x3fffffff;
+    const int cmin = wave_min_i(q.valid ? q.jj_ul : big), cmax = wave_max_i(q.valid ? q.jj_ul + 1 : -big);
+    const int rmin = wave_min_i(q.valid ? q.ii_ul : big), rmax = wave_max_i(q.valid ? q.ii_ul + 1 : -big);
+    const int tiles_x = (cmax - cmin) / 8 + 1, tiles_y = (rmax - rmin) / 8 + 1;
+    if (tiles_x * tiles_y > kSplatTiles) return q.valid ? bilinear_splat_lane(image, W, H, q) : 0;  // wave-uniform
+    if (q.valid) {
+        lds.head[lane] = make_float4(__int_as_float(q.ii_ul), __int_as_float(q.jj_ul), q.inc[0], q.inc[1]);
+        lds.head2[lane] = make_int2(__float_as_int(q.inc[2]), __float_as_int(q.inc[3]));
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int taps = 0;
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const int tc = cmin + 8 * tx, tr = rmin + 8 * ty;
+            const bool touch = q.valid && q.jj_ul <= tc + 7 && q.jj_ul + 1 >= tc && q.ii_ul <= tr + 7 && q.ii_ul + 1 >= tr;
+            unsigned long long rays = __ballot(touch);
+            if (rays == 0) continue;
+            const int jj = tc + (lane & 7), ii = tr + (lane >> 3);
+            const bool lands = tap_lands(ii, jj, W, H);
+            double sum = 0.0;
+            while (rays != 0) {
+                const int r = __ffsll((long long)rays) - 1;
+                rays &= rays - 1;
+                const float4 h = lds.head[r];
+                const int2 h2 = lds.head2[r];
+                const int di = ii - __float_as_int(h.x), dj = jj - __float_as_int(h.y);
+                if (lands && (unsigned)di <= 1u && (unsigned)dj <= 1u) {
+                    const float inc = di ? (dj ? __int_as_float(h2.y) : __int_as_float(h2.x)) : (dj ? h.w : h.z);
+                    sum += (double)inc;
+                    taps++;
+                }
+            }
+            if (lands && sum != 0.0) atomicAdd(&image[(long)(ii - 1) * W + jj - 1], sum);
+        }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return taps;
 }
 
 }  // namespace photon

@@ -21,6 +21,7 @@ struct VolumeDev {
     float data_min;
     int interpolation;          // 1 trilinear, 2 tricubic
     float weight_scale;         // trilinear weights: 0 = exact f32, 256 = NVIDIA texture-unit emulation (8 fractional bits)
+    float weight_inv;           // 1 / weight_scale (a power of two: exact), 0 when weight_scale is 0
     const f4 *texels;           // grad n (xyz), n-1 (w)   [nz][ny][nx]
     const f4 *coeffs;           // B-spline coefficients    [nz][ny][nx] (interpolation == 2)
 };
@@ -34,8 +35,9 @@ __device__ __forceinline__ f4 lerp4(f4 a, f4 b, float t) {
 // CUDA's linear texture filter keeps the interpolation weights in 9-bit fixed point with 8 fractional bits
 // (CUDA C Programming Guide, "Linear Filtering"): that is the arithmetic the reference's tex3D() calls run
 // with on its own hardware.  weight_scale = 256 reproduces it (round to nearest), 0 keeps exact f32 weights.
-__device__ __forceinline__ float quant_weight(float a, float scale) {
-    return scale > 0.f ? floorf(a * scale + 0.5f) / scale : a;
+// scale = 2^bits: the division is an exact multiplication by 2^-bits (no f32 divide sequence in the sampler)
+__device__ __forceinline__ float quant_weight(float a, float scale, float inv) {
+    return scale > 0.f ? floorf(a * scale + 0.5f) * inv : a;
 }
 __device__ __forceinline__ f4 ldtexel(const f4 *p) {
     const float4 v = *reinterpret_cast<const float4 *>(p);      // one global_load_dwordx4
@@ -47,8 +49,8 @@ __device__ __forceinline__ f4 ldtexel(const f4 *p) {
 __device__ __forceinline__ f4 tex3d_linear(const VolumeDev &v, float x, float y, float z) {
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
-    const float a = quant_weight(xb - fi, v.weight_scale), b = quant_weight(yb - fj, v.weight_scale),
-                c = quant_weight(zb - fk, v.weight_scale);
+    const float a = quant_weight(xb - fi, v.weight_scale, v.weight_inv), b = quant_weight(yb - fj, v.weight_scale, v.weight_inv),
+                c = quant_weight(zb - fk, v.weight_scale, v.weight_inv);
     const int i0 = clampi((int)fi, 0, v.nx - 1), i1 = clampi((int)fi + 1, 0, v.nx - 1);
     const int j0 = clampi((int)fj, 0, v.ny - 1), j1 = clampi((int)fj + 1, 0, v.ny - 1);
     const int k0 = clampi((int)fk, 0, v.nz - 1), k1 = clampi((int)fk + 1, 0, v.nz - 1);

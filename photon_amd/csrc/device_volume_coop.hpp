@@ -188,11 +188,11 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
 // reason as cubic_gather_fn: it is the rare path and would otherwise sit, with its eight address
 // computations, at every sampler call site of the march.
 __device__ __attribute__((noinline)) f4 linear_gather_fn(const f4 *__restrict__ tex, int nx, int ny, int nz, float x,
-                                                         float y, float z, float weight_scale) {
+                                                         float y, float z, float weight_scale, float weight_inv) {
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
-    return linear_taps<true>(tex, nx, ny, nz, (int)fi, (int)fj, (int)fk, quant_weight(xb - fi, weight_scale),
-                             quant_weight(yb - fj, weight_scale), quant_weight(zb - fk, weight_scale));
+    return linear_taps<true>(tex, nx, ny, nz, (int)fi, (int)fj, (int)fk, quant_weight(xb - fi, weight_scale, weight_inv),
+                             quant_weight(yb - fj, weight_scale, weight_inv), quant_weight(zb - fk, weight_scale, weight_inv));
 }
 
 __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
@@ -202,7 +202,8 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
     float a = xb - fi, b = yb - fj, c = zb - fk;
     if (v.weight_scale > 0.f) {                                  // wave-uniform: texture-unit weights (8 fractional bits)
-        a = quant_weight(a, v.weight_scale); b = quant_weight(b, v.weight_scale); c = quant_weight(c, v.weight_scale);
+        a = quant_weight(a, v.weight_scale, v.weight_inv); b = quant_weight(b, v.weight_scale, v.weight_inv);
+        c = quant_weight(c, v.weight_scale, v.weight_inv);
     }
     const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
     const int lane = threadIdx.x & 63;
@@ -274,7 +275,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         __builtin_amdgcn_wave_barrier();
         todo = __ballot(!done);
     }
-    if (!done) acc = linear_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z, v.weight_scale);
+    if (!done) acc = linear_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z, v.weight_scale, v.weight_inv);
     return acc;
 }
 

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #define PHOTON_MARCH_WAVES 5
 #endif
 #ifndef PHOTON_MARCH_WAVES_LINEAR
-#define PHOTON_MARCH_WAVES_LINEAR 6     // the trilinear kernels are small enough for a sixth wave
+#define PHOTON_MARCH_WAVES_LINEAR 5     // a sixth wave (80 VGPRs) costs 20 spilled dwords in the RK4 loop: 27.7 vs 26.6 ms on C3 (r02)
 #endif
 template <int ALGO, int INTERP, bool SAVE>
 __global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
@@ -463,17 +463,21 @@ __global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigne
 #define PHOTON_SPLIT_SENSOR 1
 #endif
 #ifndef PHOTON_SENSOR_WAVES
-#define PHOTON_SENSOR_WAVES 2
+#define PHOTON_SENSOR_WAVES 4           // the cooperative splats park 8.5 KiB per wave in LDS: four blocks per CU
 #endif
 template <bool FROM_STATE, bool TRAIN, bool SPLIT>
 __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
                                                      double *image, DumpDev dump, unsigned long long *counters) {
+    __shared__ SplatLds splat_lds[4];                                   // per wave: the parked rays of the cooperative splats
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     int taps = 0;
     unsigned on_sensor = 0;
     SplatReq req;                                                       // erf splat, done wave-cooperatively below
     req.valid = false;
     req.X = req.Y = req.D = req.rfD = 0.f; req.scale = 0.0; req.c0 = req.c1 = req.r0 = req.r1 = 0;
+    TapReq tap;                                                         // 4-pixel splat, likewise
+    tap.valid = false;
+    tap.ii_ul = tap.jj_ul = 0; tap.inc[0] = tap.inc[1] = tap.inc[2] = tap.inc[3] = 0.f;
     if (r < n_rays) {
         Ray ray;
         bool alive = true;
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
                         have_fin = true;
                         on_sensor = !isnan(fin.x);
                     } else {
-                        fin = sensor_bilinear(image, ray, sc.cam, taps, sc.noise, ray_id);
+                        fin = sensor_bilinear(ray, sc.cam, tap, sc.noise, ray_id);
                         have_fin = !(isnan(fin.x) || isnan(fin.y));     // .cu:2196
                         on_sensor = have_fin;
                     }
@@ -535,8 +539,9 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
             st.radiance[r] = req.scale;
         }
     } else {
-        taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req);  // all 64 lanes
+        taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req, splat_lds[threadIdx.x >> 6]);  // all 64 lanes
     }
+    taps += bilinear_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, tap, splat_lds[threadIdx.x >> 6]);     // all 64 lanes
     wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
     wave_add(&counter_slot(counters)[CNT_ON_SENSOR], (unsigned long long)on_sensor);
 }
@@ -544,6 +549,7 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
 // Second half of the sensor stage for erf splats coming from the march (sensor_kernel<.., SPLIT=true>).
 __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void splat_kernel(unsigned n_rays, RayStateDev st, double *image, int W, int H,
                                                                          unsigned long long *counters) {
+    __shared__ SplatLds splat_lds[4];
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     SplatReq req;
     req.valid = false;
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void splat_kernel(unsigne
             req.r0 = (int)floorf(req.Y - req.rfD); req.r1 = (int)ceilf(req.Y + req.rfD);
         }
     }
-    const int taps = erf_splat_wave(image, W, H, req);                  // all 64 lanes
+    const int taps = erf_splat_wave(image, W, H, req, splat_lds[threadIdx.x >> 6]);     // all 64 lanes
     wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
 }
 
@@ -949,6 +955,7 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
     d.step_size = step;
     d.data_min = data_min;
     d.interpolation = interpolation;
+    d.weight_inv = 1.0f / 256.f;
     d.weight_scale = 256.f;             // trilinear weights as the reference's texture unit holds them (photon_volume_set_weight_bits)
     d.texels = v->d_texels;
     d.coeffs = v->d_coeffs;
@@ -983,6 +990,7 @@ int photon_volume_load_nrrd(const char *path, int interpolation, photon_volume_t
 int photon_volume_set_weight_bits(photon_volume_t *vol, int bits) {
     if (!vol || bits < 0 || bits > 23) return 1;
     vol->dev.weight_scale = bits ? (float)(1 << bits) : 0.f;
+    vol->dev.weight_inv = bits ? 1.0f / (float)(1 << bits) : 0.f;
     return 0;
 }
 
