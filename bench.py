@@ -302,11 +302,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    march_ms, iters, samples, taps, on_sensor = 0.0, 0, 0, 0, 0
+    march_ms, iters, samples, taps, on_sensor, marched = 0.0, 0, 0, 0, 0, 0
     for _ in range(args.steps):
         st = step(True)               # HIP events bracket the march kernel on the launch stream
         march_ms += st.march_ms
         iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
+        marched = st.rays_marched
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
@@ -317,11 +318,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([rays_rank, on_sensor], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([rays_rank, on_sensor, marched], dtype=torch.int64, device="cuda")
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_rays, on_sensor_total = int(cnt[0].item()), int(cnt[1].item())
+        total_rays, on_sensor_total, marched_total = int(cnt[0].item()), int(cnt[1].item()), int(cnt[2].item())
     else:
-        total_rays, on_sensor_total = rays_rank, int(on_sensor)
+        total_rays, on_sensor_total, marched_total = rays_rank, int(on_sensor), int(marched)
     value = total_rays * args.steps / elapsed * 1e-6
 
     # ---- roofline of the dominant kernel (march_kernel<rk4, interp>), this rank's launch --------
@@ -385,6 +386,9 @@ def main():
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
             "roofline": roofline, "cpu_baseline": cpu,
             "volume_build_s": round(volume_build_s, 3), "rays_on_sensor": on_sensor_total,
+            # `value` counts every ray of the job; rays dropped before the march as doomed (none for BOS cones) are in
+            # rays_total but not in rays_marched
+            "rays_marched": marched_total,
         }
         if world == 1 and not os.environ.get("PHOTON_BENCH_CHILD"):
             out["abi_call"] = time_abi_call(lib, call, interp)

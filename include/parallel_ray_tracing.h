@@ -186,6 +186,9 @@ typedef struct photon_trace_stats_t {
     uint64_t sensor_taps;           /* atomic adds issued */
     float march_ms;                 /* HIP-event time of the volume-march kernel(s) */
     float total_ms;                 /* HIP-event time of the whole trace */
+    uint64_t rays_marched;          /* rays that entered the volume march: rays_launched minus those dropped before it
+                                       because they provably die on the first aperture (photon_scene_set_skip_doomed);
+                                       0 without a volume */
 } photon_trace_stats_t;
 
 /* Select the GPU this thread's subsequent photon_* calls use (hipSetDevice). */

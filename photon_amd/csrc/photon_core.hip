@@ -108,7 +108,7 @@ struct DumpDev {                    // ray dumps (save_lightrays), indexed by ch
     int inter_slots;
 };
 
-enum { CNT_ON_SENSOR = 0, CNT_ITER = 1, CNT_SAMPLES = 2, CNT_TAPS = 3, CNT_N = 4 };
+enum { CNT_ON_SENSOR = 0, CNT_ITER = 1, CNT_SAMPLES = 2, CNT_TAPS = 3, CNT_MARCHED = 4, CNT_N = 5 };
 // Statistics counters are kept in kCounterSlots copies (one 64-byte line each) and summed on the host: with one
 // copy every wave of a launch ends on an atomic to the SAME address, and 1.6e5 same-address device-scope atomics
 // serialise into ~2 ms -- more than the rest of the sensor stage (measured).
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOT
         d = mk3(st.dx[r], st.dy[r], st.dz[r]);
         marching = !isnan3(p);                                  // rays marked dead by raygen_kernel stay out of the march
     }
+    const unsigned n_marched = (unsigned)__popcll(__ballot(marching));     // rays that enter the march (not skipped as doomed)
     const GradNoise gn{noise.add_ngrad, noise.ngrad_std, noise.seed, ray_base + r};
     idump.ray = r;                                              // chunk-global ray id, like the final dumps
     trace_volume_coop<ALGO, INTERP, SAVE, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOT
         unsigned long long *slot = counter_slot(counters);
         if (mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)mc.iterations);
         if (mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)mc.samples);
+        if (n_marched) atomicAdd(&slot[CNT_MARCHED], (unsigned long long)n_marched);
     }
 }
 
@@ -444,10 +446,12 @@ __global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigne
                                                           unsigned long long *__restrict__ counters) {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     MarchCount mc{0, 0};
+    unsigned marched = 0;
     if (r < n_rays) {
         f3 p = mk3(st.px[r], st.py[r], st.pz[r]);
         f3 d = mk3(st.dx[r], st.dy[r], st.dz[r]);
         if (!isnan3(p)) {
+            marched = 1;
             trace_volume_extra<ALGO>(p, d, vol, mc);
             st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
             st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
@@ -455,6 +459,7 @@ __global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigne
     }
     wave_add(&counter_slot(counters)[CNT_ITER], (unsigned long long)mc.iterations);
     wave_add(&counter_slot(counters)[CNT_SAMPLES], (unsigned long long)mc.samples);
+    wave_add(&counter_slot(counters)[CNT_MARCHED], (unsigned long long)marched);
 }
 
 // Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241).  FROM_STATE=false
@@ -1568,7 +1573,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
             PH_CHECK(hipEventSynchronize(scene->ev[3]));
             std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
             PH_CHECK(hipMemcpy(slots.data(), scene->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            unsigned long long c[CNT_N] = {0, 0, 0, 0};
+            unsigned long long c[CNT_N] = {0, 0, 0, 0, 0};
             for (int k = 0; k < kCounterSlots; k++)
                 for (int j = 0; j < CNT_N; j++) c[j] += slots[(size_t)k * kCounterStride + j];
             memset(stats, 0, sizeof *stats);
@@ -1577,6 +1582,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
             stats->rk_iterations = c[CNT_ITER];
             stats->volume_samples = c[CNT_SAMPLES];
             stats->sensor_taps = c[CNT_TAPS];
+            stats->rays_marched = vol ? c[CNT_MARCHED] : 0;
             stats->march_ms = march_ms;
             PH_CHECK(hipEventElapsedTime(&stats->total_ms, scene->ev[0], scene->ev[3]));
         }

@@ -727,6 +727,8 @@ def test_doomed_rays_are_skipped_not_missed(photon, oracle, small_volume_file, m
                 assert st.rays_on_sensor == ost.rays_on_sensor
         assert res[(0, 0)][1].rk_iterations == ost.rk_iterations
         assert res[(1, 0)][1].rk_iterations < 0.9 * ost.rk_iterations           # a good part of the cone is doomed
+        assert res[(0, 0)][1].rays_marched == call.num_rays                     # stats say how many rays were really marched
+        assert 0 < res[(1, 0)][1].rays_marched < 0.9 * call.num_rays and res[(1, 1)][1].rays_marched == res[(1, 0)][1].rays_marched
         assert res[(1, 1)][1].rk_iterations == res[(1, 0)][1].rk_iterations
         scene.free()
     bos = scenes.bos_scene(n_dots=5, points_per_dot=20, rays_per_source=100, density_grad_filename=small_volume_file)
