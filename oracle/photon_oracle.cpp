@@ -143,11 +143,15 @@ inline void bspline_weights(float f, float &w0, float &w1, float &w2, float &w3)
 }
 
 // cubicTex3D: tricubic B-spline lookup on the prefiltered coefficient texture.
-// Reference fast form = 8 trilinear fetches (cubicTex3D_kernel.cu:48-81); its exact
-// equivalent is the separable 64-tap sum over texels index-1..index+2 with clamp addressing
+// Reference fast form = 8 trilinear fetches through the texture unit (cubicTex3D_kernel.cu:48-81); its exact
+// equivalent is the 64-tap sum over texels index-1..index+2 with clamp addressing, weights B(x) B(y) B(z)
 // (cubicTex3D.cu:63-90, examples/referenceCubicTexture3D/cubicFilter3D_kernel.hpp).
-// We evaluate that 64-tap form, x innermost, as an fmaf chain (defined order -> the HIP
-// kernel reproduces it bit for bit).
+// We evaluate that 64-tap sum in a DEFINED order, so that the HIP kernels reproduce it bit for bit -- the slab order:
+//   wxy[b][a] = wx[a] * wy[b]                                   (16 products)
+//   s_c       = sum over b, then a, of wxy[b][a] * T[a, b, c]   (per z-slab: a product, then 15 fmaf; x innermost)
+//   result    = wz[0] * s_0, then fmaf(wz[c], s_c, result)      (z pass)
+// (round 1 used the fully separable x, y, z order: 336 multiply-adds per sample against 288 here; the two differ by
+// reassociation only, a few ulp -- cubicTex3D.cu's own simple form associates as bx * (by * bz) per tap.)
 inline f4 tex3d_cubic(const Volume &v, float x, float y, float z) {
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
     const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
@@ -162,23 +166,22 @@ inline f4 tex3d_cubic(const Volume &v, float x, float y, float z) {
         iz[a] = clampi((int)fk - 1 + a, 0, v.nz - 1);
     }
     const size_t W = v.nx, WH = (size_t)v.nx * v.ny;
+    float wxy[4][4];
+    for (int b = 0; b < 4; b++)
+        for (int a = 0; a < 4; a++) wxy[b][a] = wx[a] * wy[b];
     float acc[4] = {0, 0, 0, 0};
     for (int c = 0; c < 4; c++) {
-        float plane[4] = {0, 0, 0, 0};
+        float s[4] = {0, 0, 0, 0};
         for (int b = 0; b < 4; b++) {
             const f4 *row = &v.coeffs[iz[c] * WH + iy[b] * W];
-            const f4 &t0 = row[ix[0]], &t1 = row[ix[1]], &t2 = row[ix[2]], &t3 = row[ix[3]];
-            float r[4] = {wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
-            r[0] = fmaf(wx[1], t1.x, r[0]); r[1] = fmaf(wx[1], t1.y, r[1]);
-            r[2] = fmaf(wx[1], t1.z, r[2]); r[3] = fmaf(wx[1], t1.w, r[3]);
-            r[0] = fmaf(wx[2], t2.x, r[0]); r[1] = fmaf(wx[2], t2.y, r[1]);
-            r[2] = fmaf(wx[2], t2.z, r[2]); r[3] = fmaf(wx[2], t2.w, r[3]);
-            r[0] = fmaf(wx[3], t3.x, r[0]); r[1] = fmaf(wx[3], t3.y, r[1]);
-            r[2] = fmaf(wx[3], t3.z, r[2]); r[3] = fmaf(wx[3], t3.w, r[3]);
-            for (int q = 0; q < 4; q++)
-                plane[q] = (b == 0) ? wy[0] * r[q] : fmaf(wy[b], r[q], plane[q]);
+            for (int a = 0; a < 4; a++) {
+                const f4 &t = row[ix[a]];
+                const float w = wxy[b][a];
+                if (a == 0 && b == 0) { s[0] = w * t.x; s[1] = w * t.y; s[2] = w * t.z; s[3] = w * t.w; }
+                else { s[0] = fmaf(w, t.x, s[0]); s[1] = fmaf(w, t.y, s[1]); s[2] = fmaf(w, t.z, s[2]); s[3] = fmaf(w, t.w, s[3]); }
+            }
         }
-        for (int q = 0; q < 4; q++) acc[q] = (c == 0) ? wz[0] * plane[q] : fmaf(wz[c], plane[q], acc[q]);
+        for (int q = 0; q < 4; q++) acc[q] = (c == 0) ? wz[0] * s[q] : fmaf(wz[c], s[q], acc[q]);
     }
     return f4{acc[0], acc[1], acc[2], acc[3]};
 }

@@ -77,10 +77,11 @@ __device__ __forceinline__ void bspline_weights(float f, float &w0, float &w1, f
     w3 = 1.0f / 6.0f * squared * f;
 }
 
-// Tricubic B-spline fetch on the prefiltered coefficients: separable 64-tap sum over texels
-// floor(x-0.5)-1 .. +2 (clamped), x innermost, each level an fmaf chain starting with a plain
-// product.  This is the exact form of what the reference evaluates with 8 hardware trilinear
-// fetches (cubicTex3D_kernel.cu:48-81; 64-tap equivalent: cubicTex3D.cu:63-90).
+// Tricubic B-spline fetch on the prefiltered coefficients: the 64-tap sum over texels floor(x-0.5)-1 .. +2
+// (clamped) in the SLAB order (oracle/photon_oracle.cpp, tex3d_cubic): wxy[b][a] = wx[a] * wy[b]; per z-slab one
+// 16-tap chain (a product, then 15 fmaf, x innermost); then the z pass.  288 multiply-adds per sample.  This is
+// the exact form of what the reference evaluates with 8 hardware trilinear fetches (cubicTex3D_kernel.cu:48-81;
+// 64-tap equivalent: cubicTex3D.cu:63-90).
 __device__ __forceinline__ f4 tex3d_cubic(const VolumeDev &v, float x, float y, float z) {
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
     const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
@@ -99,23 +100,20 @@ __device__ __forceinline__ f4 tex3d_cubic(const VolumeDev &v, float x, float y, 
     f4 acc = f4{0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        f4 plane = f4{0, 0, 0, 0};
+        f4 s = f4{0, 0, 0, 0};
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const f4 *row = v.coeffs + iz[c] * WH + iy[b] * W;
-            const f4 t0 = ldtexel(row + ix[0]), t1 = ldtexel(row + ix[1]);
-            const f4 t2 = ldtexel(row + ix[2]), t3 = ldtexel(row + ix[3]);
-            f4 r = f4{wx[0] * t0.x, wx[0] * t0.y, wx[0] * t0.z, wx[0] * t0.w};
-            r = f4{fmaf(wx[1], t1.x, r.x), fmaf(wx[1], t1.y, r.y), fmaf(wx[1], t1.z, r.z), fmaf(wx[1], t1.w, r.w)};
-            r = f4{fmaf(wx[2], t2.x, r.x), fmaf(wx[2], t2.y, r.y), fmaf(wx[2], t2.z, r.z), fmaf(wx[2], t2.w, r.w)};
-            r = f4{fmaf(wx[3], t3.x, r.x), fmaf(wx[3], t3.y, r.y), fmaf(wx[3], t3.z, r.z), fmaf(wx[3], t3.w, r.w)};
-            if (b == 0) plane = f4{wy[0] * r.x, wy[0] * r.y, wy[0] * r.z, wy[0] * r.w};
-            else plane = f4{fmaf(wy[b], r.x, plane.x), fmaf(wy[b], r.y, plane.y), fmaf(wy[b], r.z, plane.z),
-                            fmaf(wy[b], r.w, plane.w)};
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const f4 t = ldtexel(row + ix[a]);
+                const float w = wx[a] * wy[b];
+                if (a == 0 && b == 0) s = f4{w * t.x, w * t.y, w * t.z, w * t.w};
+                else s = f4{fmaf(w, t.x, s.x), fmaf(w, t.y, s.y), fmaf(w, t.z, s.z), fmaf(w, t.w, s.w)};
+            }
         }
-        if (c == 0) acc = f4{wz[0] * plane.x, wz[0] * plane.y, wz[0] * plane.z, wz[0] * plane.w};
-        else acc = f4{fmaf(wz[c], plane.x, acc.x), fmaf(wz[c], plane.y, acc.y), fmaf(wz[c], plane.z, acc.z),
-                      fmaf(wz[c], plane.w, acc.w)};
+        if (c == 0) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
+        else acc = f4{fmaf(wz[c], s.x, acc.x), fmaf(wz[c], s.y, acc.y), fmaf(wz[c], s.z, acc.z), fmaf(wz[c], s.w, acc.w)};
     }
     return acc;
 }
@@ -339,27 +337,22 @@ __device__ __attribute__((noinline)) f4 cubic_gather_fn(const f4 *__restrict__ t
 #pragma unroll 1
     for (int c = 0; c < 4; c++) {
         const unsigned slab = (unsigned)clampi(k - 1 + c, 0, nz - 1) * (unsigned)ny;
-        f4 plane = f4{0, 0, 0, 0};
+        f4 s = f4{0, 0, 0, 0};
 #pragma unroll 1
         for (int b = 0; b < 4; b++) {
             const unsigned row = (slab + (unsigned)clampi(j - 1 + b, 0, ny - 1)) * (unsigned)nx;
-            f4 r = f4{0, 0, 0, 0};
+            const float wyb = bspline_weight_at(fy, b);
 #pragma unroll 1
             for (int a = 0; a < 4; a++) {
                 const f4 t = ldtexel(tex + (row + (unsigned)clampi(i - 1 + a, 0, nx - 1)));
-                const float w = bspline_weight_at(fx, a);
-                if (a == 0) r = f4{w * t.x, w * t.y, w * t.z, w * t.w};
-                else r = f4{fmaf(w, t.x, r.x), fmaf(w, t.y, r.y), fmaf(w, t.z, r.z), fmaf(w, t.w, r.w)};
+                const float w = bspline_weight_at(fx, a) * wyb;        // wxy[b][a] of the slab order
+                if (a == 0 && b == 0) s = f4{w * t.x, w * t.y, w * t.z, w * t.w};
+                else s = f4{fmaf(w, t.x, s.x), fmaf(w, t.y, s.y), fmaf(w, t.z, s.z), fmaf(w, t.w, s.w)};
             }
-            const float wyb = bspline_weight_at(fy, b);
-            if (b == 0) plane = f4{wyb * r.x, wyb * r.y, wyb * r.z, wyb * r.w};
-            else plane = f4{fmaf(wyb, r.x, plane.x), fmaf(wyb, r.y, plane.y), fmaf(wyb, r.z, plane.z),
-                            fmaf(wyb, r.w, plane.w)};
         }
         const float wzc = bspline_weight_at(fz, c);
-        if (c == 0) acc = f4{wzc * plane.x, wzc * plane.y, wzc * plane.z, wzc * plane.w};
-        else acc = f4{fmaf(wzc, plane.x, acc.x), fmaf(wzc, plane.y, acc.y), fmaf(wzc, plane.z, acc.z),
-                      fmaf(wzc, plane.w, acc.w)};
+        if (c == 0) acc = f4{wzc * s.x, wzc * s.y, wzc * s.z, wzc * s.w};
+        else acc = f4{fmaf(wzc, s.x, acc.x), fmaf(wzc, s.y, acc.y), fmaf(wzc, s.z, acc.z), fmaf(wzc, s.w, acc.w)};
     }
     return acc;
 }

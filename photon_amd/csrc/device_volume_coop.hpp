@@ -37,7 +37,7 @@ namespace photon {
 #define PHOTON_TILE_REUSE 1
 #endif
 
-// 64-tap separable sum over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
+// 64-tap sum (slab order) over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
 // is one broadcast ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues
 // in 4 cycles against 2 for v_fma_f32 (measured, tools/ubench/fma_rate.hip), so packing buys no
 // throughput and costs the (w,w) operand splats; the library is built with -fno-slp-vectorize.
@@ -63,37 +63,34 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #pragma unroll
         for (int a = 0; a < 4; a++) t[r % D][a] = ldtexel(blk + (r >> 2) * SS + (r & 3) * RS + a);
     }
-    f4 acc = f4{0, 0, 0, 0}, plane = f4{0, 0, 0, 0};
-    float wx0 = wx[0];
+    // slab order (oracle/photon_oracle.cpp, tex3d_cubic): 16 products wxy[b][a] = wx[a] * wy[b], each z-slab ONE 16-tap
+    // chain (a product, then 15 fmaf per channel), then the z pass: 16 + 256 + 16 = 288 VALU instructions per sample
+    // (the fully separable x, y, z order of round 1 took 336: C3 march 66.3 -> 63.5 ms)
+    float wxy[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) wxy[b][a] = wx[a] * wy[b];
+    f4 acc = f4{0, 0, 0, 0}, s = f4{0, 0, 0, 0};
+    float w0 = wxy[0][0];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        // one read of row r+AHEAD, then one tap (4 FMAs) of row r, four times: the reads reach the LDS pipe spread
-        // out instead of in bursts of four.  The row's FMAs start from wx0: routing it through the barrier keeps
-        // them BELOW the read just issued (ALU instructions are otherwise free to move above a memory barrier,
-        // which shrinks the read-ahead distance)
         const int b = r & 3, c = r >> 2;
         const int rn = r + PHOTON_LDS_AHEAD;
-        f4 q = f4{0, 0, 0, 0};
 #pragma unroll
         for (int a = 0; a < 4; a++) {
             if (rn < 16) t[rn % D][a] = ldtexel(blk + (rn >> 2) * SS + (rn & 3) * RS + a);
-            asm volatile("" : "+v"(wx0) : : "memory");
+            asm volatile("" : "+v"(w0) : : "memory");
             const f4 ta = t[r % D][a];
-            const float w = a == 0 ? wx0 : wx[a];
-            if (a == 0) q = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
-            else q = f4{fmaf(w, ta.x, q.x), fmaf(w, ta.y, q.y), fmaf(w, ta.z, q.z), fmaf(w, ta.w, q.w)};
-            if (a < 3) asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w) : : "memory");
+            const float w = (a == 0 && b == 0) ? w0 : wxy[b][a];
+            if (a == 0 && b == 0) s = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
+            else s = f4{fmaf(w, ta.x, s.x), fmaf(w, ta.y, s.y), fmaf(w, ta.z, s.z), fmaf(w, ta.w, s.w)};
+            asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w) : : "memory");
         }
-        if (b == 0) plane = f4{wy[0] * q.x, wy[0] * q.y, wy[0] * q.z, wy[0] * q.w};
-        else plane = f4{fmaf(wy[b], q.x, plane.x), fmaf(wy[b], q.y, plane.y), fmaf(wy[b], q.z, plane.z),
-                        fmaf(wy[b], q.w, plane.w)};
         if (b == 3) {
-            if (c == 0) acc = f4{wz[0] * plane.x, wz[0] * plane.y, wz[0] * plane.z, wz[0] * plane.w};
-            else acc = f4{fmaf(wz[c], plane.x, acc.x), fmaf(wz[c], plane.y, acc.y), fmaf(wz[c], plane.z, acc.z),
-                          fmaf(wz[c], plane.w, acc.w)};
+            if (c == 0) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
+            else acc = f4{fmaf(wz[c], s.x, acc.x), fmaf(wz[c], s.y, acc.y), fmaf(wz[c], s.z, acc.z), fmaf(wz[c], s.w, acc.w)};
             asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
-        } else {
-            asm volatile("" : "+v"(plane.x), "+v"(plane.y), "+v"(plane.z), "+v"(plane.w) : : "memory");
         }
     }
     return acc;
