@@ -60,7 +60,7 @@ def _header_functions():
     with open(os.path.join(ROOT, "include", "parallel_ray_tracing.h")) as f:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return set(re.findall(r"\b((?:start_ray_tracing|photon_[a-z_]+))\s*\(", text))
+    return set(re.findall(r"\b((?:start_ray_tracing|photon_[a-z0-9_]+))\s*\(", text))
 
 
 def test_header_and_python_binding_declare_the_same_symbols():
