@@ -78,7 +78,7 @@ __device__ __forceinline__ void bspline_weights(float f, float &w0, float &w1, f
 }
 
 // Tricubic B-spline fetch on the prefiltered coefficients: the 64-tap sum over texels floor(x-0.5)-1 .. +2
-// (clamped) in the SLAB order (oracle/photon_oracle.cpp, tex3d_cubic): wxy[b][a] = wx[a] * wy[b]; per z-slab one
+// (clamped) in the SLAB order -- the defined evaluation order of the 64-tap sum, also the CPU checker's: wxy[b][a] = wx[a] * wy[b]; per z-slab one
 // 16-tap chain (a product, then 15 fmaf, x innermost); then the z pass.  288 multiply-adds per sample.  This is
 // the exact form of what the reference evaluates with 8 hardware trilinear fetches (cubicTex3D_kernel.cu:48-81;
 // 64-tap equivalent: cubicTex3D.cu:63-90).

@@ -63,7 +63,7 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #pragma unroll
         for (int a = 0; a < 4; a++) t[r % D][a] = ldtexel(blk + (r >> 2) * SS + (r & 3) * RS + a);
     }
-    // slab order (oracle/photon_oracle.cpp, tex3d_cubic): 16 products wxy[b][a] = wx[a] * wy[b], each z-slab ONE 16-tap
+    // slab order (device_volume.hpp, tex3d_cubic): 16 products wxy[b][a] = wx[a] * wy[b], each z-slab ONE 16-tap
     // chain (a product, then 15 fmaf per channel), then the z pass: 16 + 256 + 16 = 288 VALU instructions per sample
     // (the fully separable x, y, z order of round 1 took 336: C3 march 66.3 -> 63.5 ms)
     float wxy[4][4];
