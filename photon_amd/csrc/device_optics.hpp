@@ -527,20 +527,23 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
             const int col = tc + (lane & 7), row = tr + (lane >> 3);
             const bool in_image = col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1;
             double sum = 0.0;
-            while (rays != 0) {                                         // wave-uniform loop over the parked rays
-                const int r = __ffsll((long long)rays) - 1;
-                rays &= rays - 1;
+            // wave-uniform loop over the parked rays, branch-free inside (the factor reads use clamped slots, so they
+            // issue before the tests resolve and consecutive rays overlap)
+            const int r_lo = __ffsll((long long)rays) - 1, r_hi = 63 - __clzll((long long)rays);
+#pragma unroll 2
+            for (int r = r_lo; r <= r_hi; r++) {
+                if (!((rays >> r) & 1ull)) continue;                    // wave-uniform
                 const float4 h = lds.head[r];                           // broadcast reads
                 const int2 h2 = lds.head2[r];
                 const int jx = col - __float_as_int(h.w), jy = row - h2.x;
-                if (in_image && (unsigned)jx < (unsigned)(h2.y & 0xff) && (unsigned)jy < (unsigned)(h2.y >> 8)) {
-                    const float rad = sqrtf((col - h.x) * (col - h.x) + (row - h.y) * (row - h.y));
-                    if (rad <= h.z) {
-                        const float inc = (float)(lds.f[r][jx] * lds.f[r][kSplatSlots + jy]);
-                        sum += (double)inc;
-                        taps++;
-                    }
-                }
+                const double fx = lds.f[r][min((unsigned)jx, (unsigned)(kSplatSlots - 1))];
+                const double fy = lds.f[r][kSplatSlots + min((unsigned)jy, (unsigned)(kSplatSlots - 1))];
+                const float rad = sqrtf((col - h.x) * (col - h.x) + (row - h.y) * (row - h.y));
+                const bool render = in_image && (unsigned)jx < (unsigned)(h2.y & 0xff) && (unsigned)jy < (unsigned)(h2.y >> 8) &&
+                                    rad <= h.z;
+                const float inc = (float)(fx * fy);
+                sum += render ? (double)inc : 0.0;
+                taps += render ? 1 : 0;
             }
             if (sum != 0.0) atomicAdd(&image[(size_t)row * W + col], sum);
         }
