@@ -1,0 +1,47 @@
+"""bench.py end to end on the GPU at a small size: the JSON contract the driver parses, the roofline object, the live
+HBM-traffic measurement (child rocprofv3 --pmc passes) and the CPU-baseline leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PHOTON_DEVICES", "PHOTON_INTERP")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--dots", "6",
+                        "--volume", "48", *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode("utf-8", "replace")[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                              # ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_contract(photon):
+    d = _bench("--cpu-sample-rays", "20000", "--check")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["rays_on_sensor"] > 0 and d["rays_marched"] == d["config"]["rays_total"] == 6 * 100 * 500
+    r = d["roofline"]
+    assert r["bound"] == "lds" and r["unit"] == "GB/s" and 0 < r["frac"] <= 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    assert 0 < r["valu_f32"]["frac"] <= 1.0
+    # measured in this run by the child rocprofv3 passes, not read from a file
+    assert isinstance(r["traffic"], int) and r["traffic"] > 0 and r["hbm"]["source"].startswith("measured in this run")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert d["check"]["rel_l2"] <= 1e-5
+    assert d["abi_call"]["ms"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_weak_mode_and_trilinear(photon):
+    d = _bench("--cpu-sample-rays", "0", "--no-traffic", "--scaling", "weak", "--interp", "linear")
+    assert d["scaling"] == "weak" and d["roofline"]["traffic"] is None and d["cpu_baseline"] is None
+    assert "linear sampler" in d["config"]["workload"] and 0 < d["roofline"]["frac"] <= 1.0

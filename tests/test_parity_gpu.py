@@ -937,3 +937,62 @@ def test_postprocess_on_device_matches_reference(photon, golden_dir, case):
     assert abs(float(delta.std()) - 5.0) < 0.05 and abs(float(delta.mean())) < 0.05
     with pytest.raises(Exception):
         photon.postprocess_u16(d_raw.data_ptr(), W, H, d_out.data_ptr(), 0.0, 10, True, crop_rows=4 * H, crop_cols=10)
+
+
+def test_c5_full_size_properties(photon, oracle, workdir, monkeypatch):
+    """BASELINE config C5 at its full size on one GPU: 1e6 polydisperse Mie particles x 40 rays = 4e7 rays through the
+    256^3 volume (tricubic RK4, full-aperture cones -> lens-major order over device-sorted sources, doomed rays skipped).
+    Invariants at full size -- two shards = whole (what the 8-GPU split relies on), doomed-ray skip and ray order leave
+    image and rays_on_sensor unchanged on a 1e5-particle cut, the statistics add up -- and a leading slice of the same
+    particle list against the oracle."""
+    import torch
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    call = scenes.config("C5", workdir)
+    assert call.num_sources == 1_000_000 and call.num_rays == 40_000_000
+    scene = photon.scene_create(call)
+    vol = photon.volume_load_nrrd(call.density_grad_filename, 2)
+    H, W = call.image_shape
+    full = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    st = scene.trace(full.data_ptr(), vol, 2, want_stats=True)
+    assert st.rays_launched == call.num_rays
+    assert 0.5 * call.num_rays < st.rays_marched < call.num_rays          # part of every full-aperture cone is doomed
+    assert 0.3 * call.num_rays < st.rays_on_sensor < st.rays_marched
+    assert st.rk_iterations > 150 * st.rays_on_sensor
+    parts = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    cut = call.num_sources // 2 + 13
+    scene.trace(parts.data_ptr(), vol, 2, 0, cut)
+    scene.trace(parts.data_ptr(), vol, 2, cut, call.num_sources)
+    torch.cuda.synchronize()
+    assert rel_l2(parts.cpu().numpy(), full.cpu().numpy()) <= IMAGE_TOL
+    # ray order / doomed-ray skip on the first 1e5 particles
+    ref = None
+    for order, skip in ((1, 1), (0, 1), (1, 0)):
+        scene.set_ray_order(order)
+        scene.set_skip_doomed(skip)
+        img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+        s2 = scene.trace(img.data_ptr(), vol, 2, 0, 100_000, want_stats=True)
+        if ref is None:
+            ref = (img.cpu().numpy(), s2.rays_on_sensor)
+        else:
+            assert rel_l2(img.cpu().numpy(), ref[0]) <= IMAGE_TOL and s2.rays_on_sensor == ref[1], (order, skip)
+    scene.free()
+    vol.free()
+    # the leading 1500 particles through the C-ABI against the oracle
+    for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+        setattr(call, f, getattr(call, f)[:1500])
+    g = photon.render(call)
+    o, ost = oracle.render(call, interpolation=2)
+    assert ost.rays_on_sensor > 10_000 and rel_l2(g, o) <= IMAGE_TOL, rel_l2(g, o)
+
+
+def test_nrrd_header_cannot_drive_the_allocation(photon, tmp_path):
+    """A header whose sizes promise more data than the file holds (or absurd sizes) is rejected with an error code
+    before anything is allocated -- no exception crosses the C boundary."""
+    import ctypes
+    L = photon.lib
+    for sizes in ("60000 60000 60000", "70000 4 4", "64 64 64"):
+        p = tmp_path / "bad.nrrd"
+        p.write_bytes((f"NRRD0005\ntype: float\ndimension: 3\nsizes: {sizes}\nendian: little\nencoding: raw\n"
+                       "spacings: 1 1 1\nspace origin: (0,0,0)\n\n").encode() + b"\0" * 4096)
+        h = ctypes.c_void_p()
+        assert L.photon_volume_load_nrrd(str(p).encode(), 1, ctypes.byref(h)) != 0 and not h.value
