@@ -118,21 +118,6 @@ def launch_ranks(args) -> int:
 # --------------------------------------------------------------------------------------------------
 
 
-def measure_copy_bandwidth(nbytes: int = 1 << 30, reps: int = 5) -> float:
-    """Device-to-device copy rate (read + write bytes) in GB/s: the HBM rate a trivial kernel reaches here."""
-    import torch
-    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    b = torch.empty_like(a)
-    b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) * 1e-9
-
-
 def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source):
     """Time the oracle's ray loop (volume prebuilt, like the GPU side) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -356,7 +341,7 @@ def main():
 
     out = None
     if rank == 0:
-        roofline["hbm"]["copy_measured_gbs"] = round(measure_copy_bandwidth(), 1)
+        roofline["hbm"]["copy_measured_gbs"] = round(lib.measure_copy_gbs(), 1)       # float4 streaming copy, read + write
         cpu = None
         if args.cpu_sample_rays > 0 and world == 1:      # the CPU baseline is reported at N=1 only
             cpu = cpu_baseline(lambda n_sources: make_call(seed=1, n_sources=n_sources), vol_path, interp,

@@ -23,6 +23,7 @@
 #define PHOTON_AMD_PARALLEL_RAY_TRACING_H_
 
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -350,6 +351,10 @@ int photon_density_gaussian_write_nrrd(const char *path, int nx, int ny, int nz,
 
 /* Library / build identification string (static storage). */
 const char *photon_version(void);
+
+/* Device-to-device float4 streaming copy of `bytes` bytes, `reps` times: read + write rate in GB/s -- the HBM rate a
+ * trivial kernel reaches on this GPU, which bench.py prints next to the 8 TB/s specification. */
+int photon_measure_copy_gbs(size_t bytes, int reps, double *gbs_out);
 
 /* ------------------------------------------------------------------------------------
  * Section 4: sensor post-processing on the device (the step right after the

@@ -573,6 +573,11 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void splat_kernel(unsigne
     wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
 }
 
+// 16 bytes per lane, grid-stride: the streaming copy the micro-architecture guide quotes as the achievable HBM rate
+__global__ __launch_bounds__(256) void copy_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // image_array is read-modify-write (parallel_ray_tracing.cu:3309,3675): fold the f64 accumulator of
 // this call into the caller's f32 image, one rounding per pixel.
 __global__ __launch_bounds__(256) void finalize_image_kernel(float *__restrict__ image, const double *__restrict__ acc,
@@ -1590,6 +1595,34 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
     });
 }
 
+
+// Device-to-device float4 copy rate (read + write bytes per second, GB/s): what a trivial streaming kernel reaches on
+// this GPU -- the "achievable HBM peak" bench.py prints next to the 8 TB/s specification.
+extern "C" int photon_measure_copy_gbs(size_t bytes, int reps, double *gbs_out) {
+    if (!gbs_out || bytes < 4096 || reps < 1) return 1;
+    const size_t n = bytes / sizeof(float4);
+    DeviceBuffer<float4> a, b;
+    PH_CHECK(a.alloc(n));
+    PH_CHECK(b.alloc(n));
+    PH_CHECK(hipMemset(a.p, 0, n * sizeof(float4)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    PH_CHECK(hipEventCreate(&e0));
+    PH_CHECK(hipEventCreate(&e1));
+    const dim3 grid(256 * 16), block(256);
+    hipLaunchKernelGGL(copy_float4_kernel, grid, block, 0, 0, a.p, b.p, n);          // warm-up
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(copy_float4_kernel, grid, block, 0, 0, a.p, b.p, n);
+    (void)hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    PH_CHECK(e);
+    PH_CHECK(hipGetLastError());
+    *gbs_out = ms > 0.f ? 2.0 * (double)(n * sizeof(float4)) * reps / (ms * 1e-3) * 1e-9 : 0.0;
+    return 0;
+}
 
 // Sensor post-processing of perform_ray_tracing_03.py:2190-2259 on the device.
 extern "C" int photon_postprocess_u16(float *d_image, int width, int height, float pixel_gain, int pixel_bit_depth,

@@ -26,7 +26,7 @@ DECLARED_SYMBOLS = (
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
     "photon_scene_create_from_sources", "photon_volume_gaussian", "photon_density_gaussian_write_nrrd",
     # section 4: sensor post-processing on the device
-    "photon_postprocess_u16",
+    "photon_postprocess_u16", "photon_measure_copy_gbs",
 )
 
 
@@ -148,6 +148,13 @@ class PhotonLibrary:
             image = call.new_image()
         call.invoke(self.start_ray_tracing, image)
         return image
+
+    def measure_copy_gbs(self, nbytes: int = 1 << 30, reps: int = 5) -> float:
+        """Device-to-device float4 copy rate (read + write), GB/s."""
+        out = ctypes.c_double(0.0)
+        self.lib.photon_measure_copy_gbs.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        self._check(self.lib.photon_measure_copy_gbs(int(nbytes), int(reps), ctypes.byref(out)), "photon_measure_copy_gbs")
+        return out.value
 
     # ---- sensor post-processing on the device (perform_ray_tracing_03.py:2190-2259) -----------------
     def postprocess_u16(self, d_image_ptr: int, width: int, height: int, d_out_ptr: int, pixel_gain: float,
