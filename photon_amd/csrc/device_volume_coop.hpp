@@ -42,27 +42,13 @@ namespace photon {
 // in 4 cycles against 2 for v_fma_f32 (measured, tools/ubench/fma_rate.hip), so packing buys no
 // throughput and costs the (w,w) operand splats; the library is built with -fno-slp-vectorize.
 //
-// Written as a rolling pipeline over the 16 texel rows: the reads of row r+PHOTON_LDS_AHEAD are issued
-// before the FMAs of row r, so a wave keeps the LDS pipe and the VALU busy at the same time instead of
-// alternating "read a slab / wait / 84 FMAs" (C3: 83.9 -> 80.0 ms).  The asm statements pin that
-// order -- left alone the scheduler hoists all 64 reads to the top (256 VGPRs of texels, one wave per
-// SIMD); LDS returns data in order, so the compiler's s_waitcnt lgkmcnt(N) lets row r start while the
-// later rows are still in flight.
-#ifndef PHOTON_LDS_AHEAD
-#define PHOTON_LDS_AHEAD 1          // rows read ahead (16 VGPRs each); 1, 2, 3 measure the same, 1 is the leanest
-#endif
+// Written as a rolling pipeline over the 16 texel rows (C3: 83.9 -> 80.0 ms when it was introduced); LDS returns
+// data in order, so the compiler's s_waitcnt lgkmcnt(N) lets a tap start while the later reads are still in flight.
 // RS / SS: texels between consecutive rows / z-slabs of the parked data (4 / 16 for the 4x4x4 tile, 8 / 64
 // for the 8x8x4 brick of incoherent waves).
 template <int RS, int SS>
 __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4], const float (&wy)[4],
                                              const float (&wz)[4]) {
-    constexpr int D = PHOTON_LDS_AHEAD + 1;                     // ring of rows in registers
-    f4 t[D][4];
-#pragma unroll
-    for (int r = 0; r < PHOTON_LDS_AHEAD; r++) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) t[r % D][a] = ldtexel(blk + (r >> 2) * SS + (r & 3) * RS + a);
-    }
     // slab order (device_volume.hpp, tex3d_cubic): 16 products wxy[b][a] = wx[a] * wy[b], each z-slab ONE 16-tap
     // chain (a product, then 15 fmaf per channel), then the z pass: 16 + 256 + 16 = 288 VALU instructions per sample
     // (the fully separable x, y, z order of round 1 took 336: C3 march 66.3 -> 63.5 ms)
@@ -73,19 +59,27 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
         for (int a = 0; a < 4; a++) wxy[b][a] = wx[a] * wy[b];
     f4 acc = f4{0, 0, 0, 0}, s = f4{0, 0, 0, 0};
     float w0 = wxy[0][0];
+    // ONE row of texels in registers (16 VGPRs): texel (r+1, a) is read into the slot of texel (r, a) right after that
+    // one's four FMAs have been issued -- in-order issue: they have read their operands before the later read lands --
+    // so every read runs three taps (12 FMAs) ahead of its use and the LDS pipe and the VALU stay busy together
+    // instead of alternating "read a slab / wait / FMAs" (round 1 kept a two-row ring, 32 VGPRs, reads of row r+1
+    // before the FMAs of row r: 63.0 -> 62.6 ms on C3 and 4 spilled dwords instead of 8).  The asm statements pin the
+    // order -- left alone the scheduler hoists all 64 reads to the top (256 VGPRs of texels, one wave per SIMD).
+    f4 t[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) t[a] = ldtexel(blk + a);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int b = r & 3, c = r >> 2;
-        const int rn = r + PHOTON_LDS_AHEAD;
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            if (rn < 16) t[rn % D][a] = ldtexel(blk + (rn >> 2) * SS + (rn & 3) * RS + a);
-            asm volatile("" : "+v"(w0) : : "memory");
-            const f4 ta = t[r % D][a];
+            const f4 ta = t[a];
             const float w = (a == 0 && b == 0) ? w0 : wxy[b][a];
             if (a == 0 && b == 0) s = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
             else s = f4{fmaf(w, ta.x, s.x), fmaf(w, ta.y, s.y), fmaf(w, ta.z, s.z), fmaf(w, ta.w, s.w)};
             asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w) : : "memory");
+            if (r < 15) t[a] = ldtexel(blk + ((r + 1) >> 2) * SS + ((r + 1) & 3) * RS + a);
+            asm volatile("" : "+v"(w0) : : "memory");
         }
         if (b == 3) {
             if (c == 0) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
