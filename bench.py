@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-rays", type=int, default=500000, help="rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--check", action="store_true", help="also verify a slice of the image against the oracle")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N ranks SHARING device 0, gloo reduce of host copies: exercises the N > 1 logic of this script on a "
+                         "one-GPU box (RCCL cannot put two ranks on one GPU); the line is marked as a rehearsal, not a measurement")
     return ap.parse_args(argv)
 
 
@@ -102,6 +105,8 @@ def launch_ranks(args) -> int:
     (device_count() does not), so starting children is safe; never re-execs."""
     import torch
     have = torch.cuda.device_count()
+    if args.rehearse and have >= 1:
+        have = args.gpus
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to run "
               f"{args.gpus} ranks on fewer devices", file=sys.stderr, flush=True)
@@ -229,10 +234,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.rehearse:
+        local_rank = 0                      # every rank on the one GPU of this box
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
-    if under_launcher:                      # one process per GPU over RCCL (also exercised at world_size 1)
+    if under_launcher and args.rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif under_launcher:                    # one process per GPU over RCCL (also exercised at world_size 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
@@ -274,10 +284,18 @@ def main():
     image = torch.zeros(H * W, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    comm_dev = "cpu" if args.rehearse else "cuda"      # gloo reduces host copies in a rehearsal
+
     def step(want_stats):
         image.zero_()
         st = scene.trace(image.data_ptr(), volume, args.algorithm, src_begin, src_end, stream=stream, want_stats=want_stats)
-        reduce_image(image, 0)
+        if args.rehearse and dist.is_initialized():
+            host = image.cpu()
+            reduce_image(host, 0)
+            if rank == 0:
+                image.copy_(host)
+        else:
+            reduce_image(image, 0)
         return st
 
     for _ in range(args.warmup):
@@ -300,10 +318,10 @@ def main():
     elapsed = time.perf_counter() - t0
     rays_rank = (src_end - src_begin) * args.rays_per_source
     if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([rays_rank, on_sensor, marched], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([rays_rank, on_sensor, marched], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_rays, on_sensor_total, marched_total = int(cnt[0].item()), int(cnt[1].item()), int(cnt[2].item())
     else:
@@ -368,7 +386,7 @@ def main():
                        "parallelism": (f"{world} rank(s), one per GPU; sources of ONE job split by shard_range, "
                                        if strong else f"{world} rank(s), one per GPU, one scene each; ")
                                       + "private images, one RCCL sum-reduce onto rank 0 per step",
-                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
+                       "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1) if not args.rehearse else 0},
             "roofline": roofline, "cpu_baseline": cpu,
             "volume_build_s": round(volume_build_s, 3), "rays_on_sensor": on_sensor_total,
             # `value` counts every ray of the job; rays dropped before the march as doomed (none for BOS cones) are in
@@ -377,7 +395,19 @@ def main():
         }
         if world == 1 and not os.environ.get("PHOTON_BENCH_CHILD"):
             out["abi_call"] = time_abi_call(lib, call, interp)
-        if args.check:
+        if args.rehearse:
+            out["rehearsal"] = (f"{world} ranks SHARING one GPU, gloo reduce of host copies: exercises this script's N > 1 logic; "
+                                "NOT a multi-GPU measurement")
+            # the reduced image of the sharded job against the oracle's render of the WHOLE job
+            if args.check:
+                import numpy as np
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                from oracle_lib import Oracle
+                ref, _ = Oracle().render(make_call(seed=1), interpolation=interp)
+                got = image.cpu().numpy().reshape(H, W).astype(np.float64)
+                out["check"] = {"rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "sources": call.num_sources,
+                                "what": "reduced image of all ranks vs the oracle's render of the whole job"}
+        elif args.check:
             out["check"] = check_against_oracle(lib, make_call, vol_path, interp)
         print(json.dumps(out), flush=True)
     scene.free()

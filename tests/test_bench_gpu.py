@@ -45,3 +45,18 @@ def test_bench_weak_mode_and_trilinear(photon):
     d = _bench("--cpu-sample-rays", "0", "--no-traffic", "--scaling", "weak", "--interp", "linear")
     assert d["scaling"] == "weak" and d["roofline"]["traffic"] is None and d["cpu_baseline"] is None
     assert "linear sampler" in d["config"]["workload"] and 0 < d["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_three_ranks_on_one_gpu(photon):
+    """`bench.py --gpus 3 --rehearse`: the script starts its own three ranks, each traces its shard_range of the ONE
+    job on the shared GPU, the images are sum-reduced onto rank 0 -- the N > 1 logic of the bench (sharding, counters,
+    JSON) end to end; the reduced image must be the oracle's image of the whole job."""
+    d = _bench("--gpus", "3", "--rehearse", "--cpu-sample-rays", "0", "--no-traffic", "--check")
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and "rehearsal" in d
+    assert d["config"]["rays_total"] == 6 * 100 * 500 == d["rays_marched"]      # every source traced exactly once
+    assert d["roofline"]["rays_per_launch"] == 2 * 100 * 500                    # rank 0's third of the sources
+    assert d["rays_on_sensor"] == 6 * 100 * 500
+    assert d["check"]["sources"] == 600 and d["check"]["rel_l2"] <= 1e-5
+    w = _bench("--gpus", "2", "--rehearse", "--scaling", "weak", "--cpu-sample-rays", "0", "--no-traffic")
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["config"]["rays_total"] == 2 * 6 * 100 * 500
