@@ -449,3 +449,39 @@ def test_march_agrees_with_independent_ode_solution(oracle, interp, algorithm):
         worst = max(worst, float(np.linalg.norm(defl_got - defl_true) / np.linalg.norm(defl_true)))
         assert np.linalg.norm(p1[k][:2] - y_end[:2]) < 0.05                 # exit point within 0.05 um
     assert worst <= 4e-3, worst        # measured: RK4 2.2e-3 / 1.2e-3 (trilinear / tricubic), Euler 1.5e-3 / 1.9e-4
+
+
+def test_erf_splat_is_the_pixel_integral_of_a_gaussian(oracle):
+    """Independent check of row a19's constants (intersect_sensor_02, .cu:1383-1543): the spot one ray leaves must be the
+    integral over each pixel of a 2-D Gaussian of standard deviation D/4 carrying radiance * cos^4 / f#^2, cut off at
+    0.75 D from the centroid -- evaluated here with scipy's normal CDF, with only the centroid and the amplitude fitted.
+    Pins sqrt(8)/D <-> sigma = D/4, the I0 * pi/32 * 8/pi = 1/4 normalisation, the render radius, the x flip."""
+    from scipy.optimize import least_squares
+    from scipy.stats import norm
+    call = scenes.bos_scene(n_dots=1, points_per_dot=1, rays_per_source=1, seed=3)       # one source, its chief ray
+    call.src_x, call.src_y = np.array([900.0]), np.array([-1350.0])
+    img = oracle.render(call)[0].astype(np.float64)
+    D = call.camera["diffraction_diameter"]
+    sig = D / 4.0
+    ys, xs = np.nonzero(img)
+    assert 12 <= ys.size <= 25
+    cols, rows = np.arange(xs.min() - 2, xs.max() + 3), np.arange(ys.min() - 2, ys.max() + 3)
+    C, R = np.meshgrid(cols, rows)
+    window = img[rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1]
+
+    def resid(p):
+        X, Y, A = p
+        fx = norm.cdf((C + 0.5 - X) / sig) - norm.cdf((C - 0.5 - X) / sig)
+        fy = norm.cdf((R + 0.5 - Y) / sig) - norm.cdf((R - 0.5 - Y) / sig)
+        return (A * fx * fy * (np.sqrt((C - X) ** 2 + (R - Y) ** 2) <= 0.75 * D) - window).ravel()
+
+    x0 = [(xs * img[ys, xs]).sum() / img.sum(), (ys * img[ys, xs]).sum() / img.sum(), img.sum()]
+    sol = least_squares(resid, x0, xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    X, Y, A = sol.x
+    assert np.abs(sol.fun).max() <= 1e-6 * img.max()                                    # every pixel, f32 increments
+    assert A == pytest.approx(call.src_radiance[0] / call.aperture_f_number ** 2, rel=1e-4)      # cos^4 = 1 - 1e-5 here
+    # where the spot sits: inverted by the lens (magnification f / (z_o - f)), x mirrored by the sensor convention
+    M = 105000.0 / (700000.0 - 105000.0)
+    W, pitch = call.camera["x_pixel_number"], call.camera["pixel_pitch"]
+    assert X == pytest.approx((W - 1) - ((-M * 900.0) / pitch + (W - 1) / 2.0) - 0.5, abs=0.1)
+    assert Y == pytest.approx((-M * -1350.0) / pitch + (W - 1) / 2.0 - 0.5, abs=0.1)
