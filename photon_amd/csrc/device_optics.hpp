@@ -428,16 +428,22 @@ __device__ __forceinline__ int erf_splat_lane(double *image, int W, int H, const
     return taps;
 }
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+// Wave-wide integer min / max on the DPP network (row shifts, then the two row broadcasts; the total lands in lane 63
+// and is handed to every lane as a scalar): six dependent VALU steps, where the shuffle-based butterfly paid six
+// ds_bpermute round trips through the LDS crossbar.
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax_i(int v) {
+    auto op = [](int a, int b) { return MAX ? max(a, b) : min(a, b); };
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));       // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));       // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));       // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));       // row_shr:8 -> lane 15 of each row holds the row's result
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));       // row_bcast:15 into rows 1 and 3
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));       // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ int wave_min_i(int v) { return wave_minmax_i<false>(v); }
+__device__ __forceinline__ int wave_max_i(int v) { return wave_minmax_i<true>(v); }
 
 // ---------------------------------------------------------------------------------------------
 // Wave-cooperative splats.  The 64 rays of a wave land on a handful of neighbouring pixels (BOS: the narrow cone of
@@ -453,11 +459,19 @@ __device__ __forceinline__ int wave_max_i(int v) {
 constexpr int kSplatTiles = 6;
 constexpr int kSplatSlots = 7;              // columns / rows of one ray's window the parked layout carries (D = 3: 6 or 7)
 
-struct SplatLds {                           // one wave's area: 8.5 KiB
-    float4 head[64];                        // X, Y, rfD, bits(c0)
-    int2 head2[64];                         // r0, nw | nh << 8
-    double f[64][2 * kSplatSlots];          // scale * d_erf(column c0 + j), j < 7 | d_erf(row r0 + j)
+struct SplatLds {                           // one wave's area: 8 KiB (five 256-thread blocks per CU)
+    float4 head[64];                        // erf: X, Y, bits(c0), r0 | nw << 20 | nh << 24   4-pixel: bits(ii), bits(jj), inc0, inc1
+    double f[64][2 * kSplatSlots];          // erf: scale * d_erf(column c0 + j), j < 7 | d_erf(row r0 + j)   4-pixel: [0] = inc2, inc3
 };
+
+// largest f32 t with sqrtf(t) <= r: the radius test sqrtf(s) <= r is then s <= t, exactly (sqrtf is correctly rounded
+// and monotone), without a square root per pixel and ray
+__device__ __forceinline__ float sqrt_threshold(float r) {
+    float t = r * r;
+    while (sqrtf(t) > r) t = __uint_as_float(__float_as_uint(t) - 1u);
+    while (sqrtf(__uint_as_float(__float_as_uint(t) + 1u)) <= r) t = __uint_as_float(__float_as_uint(t) + 1u);
+    return t;
+}
 
 // Must be called by all 64 lanes of the wave.  Returns this lane's share of the number of rendered pixels (the wave's
 // total is what the callers accumulate).
@@ -470,9 +484,12 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
     const int cmin = wave_min_i(q.valid ? q.c0 : big), cmax = wave_max_i(q.valid ? q.c1 : -big);
     const int rmin = wave_min_i(q.valid ? q.r0 : big), rmax = wave_max_i(q.valid ? q.r1 : -big);
     const int tiles_x = (cmax - cmin) / 8 + 1, tiles_y = (rmax - rmin) / 8 + 1;
-    const bool fits = !q.valid || (nw <= kSplatSlots && nh <= kSplatSlots);
-    if (__ballot(!fits) != 0 || tiles_x * tiles_y > kSplatTiles)        // wave-uniform branch
+    // the render radius is a camera constant (render_fraction * D): wave-uniform; r0 travels in 20 bits
+    const float rfD = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__shfl(q.rfD, __ffsll((long long)any) - 1, 64))));
+    const bool fits = !q.valid || (nw <= kSplatSlots && nh <= kSplatSlots && q.rfD == rfD && q.r0 > -(1 << 18) && q.r0 < (1 << 18));
+    if (__ballot(!fits) != 0 || tiles_x * tiles_y > kSplatTiles || !(rfD > 0.f && rfD < 1.0e4f))     // wave-uniform branch
         return q.valid ? erf_splat_lane(image, W, H, q) : 0;
+    const float rad2_max = sqrt_threshold(rfD);
     const float sqrt8 = sqrtf(8.0f);
     // ---- park this ray's factors.  The reference evaluates erf at both edges of every pixel; neighbouring pixels share
     // an edge, and (idx - X) +- 0.5 is the same double from either side whenever the f32 difference idx - X is exact --
@@ -511,8 +528,7 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
             for (int j = 0; j < kSplatSlots; j++)
                 if (j < nh) fy[j] = erf_edge_diff(sqrt8, q.r0 + j, q.Y, q.D);
         }
-        lds.head[lane] = make_float4(q.X, q.Y, q.rfD, __int_as_float(q.c0));
-        lds.head2[lane] = make_int2(q.r0, nw | (nh << 8));
+        lds.head[lane] = make_float4(q.X, q.Y, __int_as_float(q.c0), __int_as_float((q.r0 & 0xfffff) | (nw << 20) | (nh << 24)));
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -533,14 +549,14 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
 #pragma unroll 2
             for (int r = r_lo; r <= r_hi; r++) {
                 if (!((rays >> r) & 1ull)) continue;                    // wave-uniform
-                const float4 h = lds.head[r];                           // broadcast reads
-                const int2 h2 = lds.head2[r];
-                const int jx = col - __float_as_int(h.w), jy = row - h2.x;
+                const float4 h = lds.head[r];                           // broadcast read
+                const int packed = __float_as_int(h.w);
+                const int jx = col - __float_as_int(h.z), jy = row - ((packed << 12) >> 12);       // r0: sign-extended 20 bits
                 const double fx = lds.f[r][min((unsigned)jx, (unsigned)(kSplatSlots - 1))];
                 const double fy = lds.f[r][kSplatSlots + min((unsigned)jy, (unsigned)(kSplatSlots - 1))];
-                const float rad = sqrtf((col - h.x) * (col - h.x) + (row - h.y) * (row - h.y));
-                const bool render = in_image && (unsigned)jx < (unsigned)(h2.y & 0xff) && (unsigned)jy < (unsigned)(h2.y >> 8) &&
-                                    rad <= h.z;
+                const float rad2 = (col - h.x) * (col - h.x) + (row - h.y) * (row - h.y);         // sqrtf(rad2) <= rfD  <=>  rad2 <= rad2_max
+                const bool render = in_image && (unsigned)jx < (unsigned)((packed >> 20) & 0xf) && (unsigned)jy < (unsigned)((packed >> 24) & 0xf) &&
+                                    rad2 <= rad2_max;
                 const float inc = (float)(fx * fy);
                 sum += render ? (double)inc : 0.0;
                 taps += render ? 1 : 0;
@@ -672,7 +688,7 @@ __device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, 
     if (tiles_x * tiles_y > kSplatTiles) return q.valid ? bilinear_splat_lane(image, W, H, q) : 0;  // wave-uniform
     if (q.valid) {
         lds.head[lane] = make_float4(__int_as_float(q.ii_ul), __int_as_float(q.jj_ul), q.inc[0], q.inc[1]);
-        lds.head2[lane] = make_int2(__float_as_int(q.inc[2]), __float_as_int(q.inc[3]));
+        *reinterpret_cast<float2 *>(&lds.f[lane][0]) = make_float2(q.inc[2], q.inc[3]);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -690,10 +706,10 @@ __device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, 
                 const int r = __ffsll((long long)rays) - 1;
                 rays &= rays - 1;
                 const float4 h = lds.head[r];
-                const int2 h2 = lds.head2[r];
+                const float2 h2 = *reinterpret_cast<const float2 *>(&lds.f[r][0]);
                 const int di = ii - __float_as_int(h.x), dj = jj - __float_as_int(h.y);
                 if (lands && (unsigned)di <= 1u && (unsigned)dj <= 1u) {
-                    const float inc = di ? (dj ? __int_as_float(h2.y) : __int_as_float(h2.x)) : (dj ? h.w : h.z);
+                    const float inc = di ? (dj ? h2.y : h2.x) : (dj ? h.w : h.z);
                     sum += (double)inc;
                     taps++;
                 }

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void march_extra_kernel(VolumeDev vol, unsigne
 #define PHOTON_SPLIT_SENSOR 1
 #endif
 #ifndef PHOTON_SENSOR_WAVES
-#define PHOTON_SENSOR_WAVES 4           // the cooperative splats park 8.5 KiB per wave in LDS: four blocks per CU
+#define PHOTON_SENSOR_WAVES 5           // the cooperative splats park 8 KiB per wave in LDS: five blocks per CU
 #endif
 template <bool FROM_STATE, bool TRAIN, bool SPLIT>
 __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
