@@ -57,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--volume", type=int, default=256, help="grid points per axis of the density volume")
     ap.add_argument("--dots", type=int, default=200, help="BOS dots of the job (strong) / per GPU (weak); x100 sources x500 rays")
     ap.add_argument("--rays-per-source", type=int, default=500)
-    ap.add_argument("--cpu-sample-rays", type=int, default=500000, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-rays", type=int, default=1000000, help="rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--check", action="store_true", help="also verify a slice of the image against the oracle")
     ap.add_argument("--rehearse", action="store_true",
