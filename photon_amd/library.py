@@ -55,6 +55,24 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _one_hip_runtime_per_process():
+    """PyTorch-ROCm bundles its own libamdhip64; the library's RUNPATH names the system's.  A process that ends up with
+    both mapped has two HIP runtimes, and whichever touches the GPU second finds no device (seen both ways round on
+    the MI355X boxes).  Loaded FIRST, torch's copy is the one the library binds to by SONAME -- so when torch is
+    installed (this repo's tests, bench and smoke use it for device tensors and torch.distributed) it is imported before
+    the library is mapped.  photon itself has no torch: the library then maps the system runtime on its own.
+    PHOTON_NO_TORCH_PRELOAD=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("PHOTON_NO_TORCH_PRELOAD"):
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:       # noqa: BLE001  -- a broken torch must not keep the library from loading
+        pass
+
+
 class PhotonLibrary:
     def __init__(self, path: Optional[str] = None, build: bool = True):
         if path is None:
@@ -71,6 +89,7 @@ class PhotonLibrary:
             raise PhotonError(f"{path} not found: build it with `python -m photon_amd.build` "
                               "(there is no CPU fallback)")
         self.path = path
+        _one_hip_runtime_per_process()
         self.lib = ctypes.CDLL(path)
         L = self.lib
         self.start_ray_tracing = bind_start_ray_tracing(L)
