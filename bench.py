@@ -150,6 +150,8 @@ def measure_hbm_traffic(args, kernel_tag: str):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, {"source": "unavailable: rocprofv3 not found"}
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, {"source": "unavailable: this run is itself under a profiler (no nested rocprofv3 passes)"}
     means = {}
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory(prefix="photon_pmc_", dir="/tmp") as tmp:
@@ -163,7 +165,7 @@ def measure_hbm_traffic(args, kernel_tag: str):
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
                 env.pop(k, None)
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
             except subprocess.TimeoutExpired:
                 return None, {"source": f"unavailable: rocprofv3 --pmc {counter} pass timed out"}
             vals = []
