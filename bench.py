@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # HBM3E spec (6.29 TB/s measured float4 copy)
 LDS_PEAK_GBS = 150000.0          # aggregate ds_read_b64/b128 rate with every CU streaming (256 B/clk/CU x 256 CUs x 2.4 GHz)
+LDS_BYTES_PER_CLK = 256 * 256    # ds_read_b128: 256 B/clk/CU x 256 CUs -- times the MEASURED shader clock = peak at that clock
 VALU_F32_PEAK_TFLOPS = 157.3     # vector f32 (256 CUs x 4 SIMD x 32 lanes/clk FMA x 2.4 GHz x 2)
 TEXELS_PER_SAMPLE = {1: 8, 2: 64}
 
@@ -123,23 +124,66 @@ def launch_ranks(args) -> int:
 # --------------------------------------------------------------------------------------------------
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source):
-    """Time the oracle's ray loop (volume prebuilt, like the GPU side) on a bounded sample."""
+    """The CPU oracle (scalar C++ restatement of the reference's device code, OpenMP over sources) on bounded samples of
+    the same workload, BASELINE.md section 2: the C3 ray loop on all host cores (`value`) and on one thread, the same
+    slice through the start_ray_tracing-shaped entry point (NRRD parse + volume build included), and the two small
+    configurations C0 / C2.  About 25 s of CPU work in total."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle_lib import Oracle
+    from photon_amd import scenes
     o = Oracle()
-    o.set_num_threads(cpu_budget())
-    n_src = max(1, sample_rays // rays_per_source)
-    call = call_factory(n_sources=n_src)
-    vol = o.volume_load_nrrd(volume_path, interp)
+    cores = cpu_budget()
+    o.set_num_threads(cores)
+
+    def loop_rate(n_src, threads):
+        o.set_num_threads(threads)
+        call = call_factory(n_sources=n_src)
+        vol = o.volume_load_nrrd(volume_path, interp)
+        t0 = time.perf_counter()
+        o.render_with_volume(call, vol)
+        dt = time.perf_counter() - t0
+        vol.free()
+        return n_src * rays_per_source / dt * 1e-6, dt
+
+    n_src = max(1, sample_rays // 2 // rays_per_source)
+    rate, dt = loop_rate(n_src, cores)
+    n_one = max(1, n_src // 16)
+    rate_one, dt_one = loop_rate(n_one, 1)
+    o.set_num_threads(cores)
+    n_abi = max(1, n_src // 2)
+    call = call_factory(n_sources=n_abi)
     t0 = time.perf_counter()
-    _, st = o.render_with_volume(call, vol)
-    dt = time.perf_counter() - t0
-    vol.free()
+    o.render(call, interpolation=interp)                 # the reference's argument list: parse + build + ray loop
+    dt_abi = time.perf_counter() - t0
+    legs = {}
+    for name in ("C0", "C2"):                            # PIV, no volume (BASELINE.json configs[0], configs[1])
+        c = scenes.config(name)
+        o.render(c)                                      # warm-up
+        t0 = time.perf_counter()
+        o.render(c)
+        d = time.perf_counter() - t0
+        legs[name] = {"rays": c.num_rays, "ms": round(d * 1e3, 2), "Mrays_per_s": round(c.num_rays / d * 1e-6, 3)}
     rays = n_src * rays_per_source
-    return {"value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": o.num_threads(), "kind": "port",
-            "sample": f"{rays} rays ({n_src} sources x {rays_per_source}) of the same scene and volume, "
-                      f"ray loop only (volume prebuilt), {dt:.1f} s"}
+    return {"value": rate, "unit": "Mrays/s", "cores": o.num_threads(), "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{rays} rays ({n_src} sources x {rays_per_source}) of the same scene and volume, ray loop only "
+                      f"(volume prebuilt), {dt:.1f} s; extrapolates linearly to the 1e7-ray job ({1e7 / (rate * 1e6):.0f} s)",
+            "one_thread": {"value": round(rate_one, 5), "unit": "Mrays/s", "sample": f"{n_one * rays_per_source} rays, {dt_one:.1f} s"},
+            "through_abi": {"value": round(n_abi * rays_per_source / dt_abi * 1e-6, 5), "unit": "Mrays/s",
+                            "sample": f"{n_abi * rays_per_source} rays through the start_ray_tracing-shaped entry point "
+                                      f"(NRRD parse + volume build included), {dt_abi:.1f} s"},
+            "other_configs": legs}
 
 
 def measure_hbm_traffic(args, kernel_tag: str):
@@ -303,21 +347,33 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
+    windowed = scene.has_stats_window
+    if windowed:
+        scene.stats_begin(stream)       # counters zeroed on the stream; the timed traces record HIP events, no host sync
+    torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    march_ms, iters, samples, taps, on_sensor, marched = 0.0, 0, 0, 0, 0, 0
+    march_ms, iters, samples, taps, on_sensor, marched, clock_mhz = 0.0, 0, 0, 0, 0, 0, 0.0
     for _ in range(args.steps):
-        st = step(True)               # HIP events bracket the march kernel on the launch stream
-        march_ms += st.march_ms
-        iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
-        marched = st.rays_marched
+        st = step(not windowed)       # HIP events bracket the march kernel on the launch stream
+        if not windowed:              # (a library without the statistics window: per-step stats, one host sync per step)
+            march_ms += st.march_ms
+            iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
+            marched = st.rays_marched
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if windowed:                        # sums over the K timed steps, read AFTER the timed region
+        st = scene.stats_end(stream)
+        k = max(int(st.traces), 1)
+        march_ms = st.march_ms
+        iters, samples, taps = st.rk_iterations // k, st.volume_samples // k, st.sensor_taps // k
+        on_sensor, marched = st.rays_on_sensor // k, st.rays_marched // k
+        clock_mhz = float(st.shader_clock_mhz)
     rays_rank = (src_end - src_begin) * args.rays_per_source
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
@@ -346,8 +402,15 @@ def main():
     # the kernel pulls through the LDS read pipe; they never were HBM bytes.  The bound that prices them is the LDS
     # aggregate read rate; the f32 VALU (the separable FMA chain) is the co-limiter.  For the trilinear kernel (8
     # texels per sample) neither pipe is near its peak: it is instruction-issue bound.
+    # The chip lowers its clock under load, by an amount that differs from device to device (guide, "DVFS give-back"): the
+    # march kernel stamps s_memtime / s_memrealtime per wave, so the line carries the clock it actually ran at and the
+    # fraction of the LDS read pipe AT THAT CLOCK -- the number that is comparable from box to box.
+    peak_at_clock = LDS_BYTES_PER_CLK * clock_mhz * 1e6 * 1e-9 if clock_mhz > 0 else None       # GB/s
     roofline = {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / LDS_PEAK_GBS, 4), "traffic": None,
+                "clock_mhz": round(clock_mhz, 1) if clock_mhz > 0 else None,
+                "peak_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
+                "frac_at_clock": round(achieved / peak_at_clock, 4) if peak_at_clock else None,
                 "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
                 "sensor_taps_per_ray": round(a_bar, 2), "rays_per_launch": rays_rank,

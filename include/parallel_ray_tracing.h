@@ -190,6 +190,10 @@ typedef struct photon_trace_stats_t {
     uint64_t rays_marched;          /* rays that entered the volume march: rays_launched minus those dropped before it
                                        because they provably die on the first aperture (photon_scene_set_skip_doomed);
                                        0 without a volume */
+    float shader_clock_mhz;         /* clock the march kernel actually ran at: s_memtime / s_memrealtime ticks summed over its
+                                       waves x 100 MHz (the chip lowers its clock under load, differently from device to
+                                       device); 0 without a volume */
+    uint32_t traces;                /* photon_trace calls these numbers cover (1, or the calls of a statistics window) */
 } photon_trace_stats_t;
 
 /* Select the GPU this thread's subsequent photon_* calls use (hipSetDevice). */
@@ -282,6 +286,14 @@ int photon_scene_set_skip_doomed(photon_scene_t *scene, int on);
 int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_tracing_algorithm,
                  int64_t src_begin, int64_t src_end, float *d_image, void *stream,
                  photon_trace_stats_t *stats);
+
+/* Statistics over a WINDOW of photon_trace calls with no host synchronisation inside it (a timed loop): _begin zeroes
+ * the counters on the stream; every photon_trace(..., stats = NULL) of this scene up to _end records its HIP events on
+ * its stream and lets the counters run; _end waits for the stream and returns the SUMS over the window's traces
+ * (march_ms, total_ms, the counters; shader_clock_mhz over all march waves; traces = number of calls).  The reference
+ * prints one wall-clock time per call instead (parallel_ray_tracing.cu:3498-3503, 3678-3684). */
+int photon_scene_stats_begin(photon_scene_t *scene, void *stream);
+int photon_scene_stats_end(photon_scene_t *scene, void *stream, photon_trace_stats_t *stats);
 
 /* March-only entry point for parity tests: n rays (host arrays pos/dir f32[n][3], world
  * frame) through trace_rays_through_density_gradients (.h:1455-1544); results in place,

@@ -476,7 +476,7 @@ __device__ __forceinline__ float sqrt_threshold(float r) {
 // Must be called by all 64 lanes of the wave.  Returns this lane's share of the number of rendered pixels (the wave's
 // total is what the callers accumulate).
 __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const SplatReq &q, SplatLds &lds) {
-    const unsigned long long any = __ballot(q.valid);
+    const unsigned long long any = ballot(q.valid);
     if (any == 0) return 0;
     const int lane = threadIdx.x & 63;
     const int nw = q.c1 - q.c0 + 1, nh = q.r1 - q.r0 + 1;
@@ -487,7 +487,7 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
     // the render radius is a camera constant (render_fraction * D): wave-uniform; r0 travels in 20 bits
     const float rfD = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__shfl(q.rfD, __ffsll((long long)any) - 1, 64))));
     const bool fits = !q.valid || (nw <= kSplatSlots && nh <= kSplatSlots && q.rfD == rfD && q.r0 > -(1 << 18) && q.r0 < (1 << 18));
-    if (__ballot(!fits) != 0 || tiles_x * tiles_y > kSplatTiles || !(rfD > 0.f && rfD < 1.0e4f))     // wave-uniform branch
+    if (ballot(!fits) != 0 || tiles_x * tiles_y > kSplatTiles || !(rfD > 0.f && rfD < 1.0e4f))     // wave-uniform branch
         return q.valid ? erf_splat_lane(image, W, H, q) : 0;
     const float rad2_max = sqrt_threshold(rfD);
     const float sqrt8 = sqrtf(8.0f);
@@ -538,7 +538,7 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
         for (int tx = 0; tx < tiles_x; tx++) {
             const int tc = cmin + 8 * tx, tr = rmin + 8 * ty;           // tile origin (wave-uniform)
             const bool touch = q.valid && q.c0 <= tc + 7 && q.c1 >= tc && q.r0 <= tr + 7 && q.r1 >= tr;
-            unsigned long long rays = __ballot(touch);                  // rays whose window meets this tile
+            unsigned long long rays = ballot(touch);                  // rays whose window meets this tile
             if (rays == 0) continue;
             const int col = tc + (lane & 7), row = tr + (lane >> 3);
             const bool in_image = col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1;
@@ -678,7 +678,7 @@ __device__ __forceinline__ int bilinear_splat_lane(double *image, int W, int H, 
 // 8x8 tiles of the wave's window and sum what the parked rays add to them; one atomic per pixel per wave.  Must be
 // called by all 64 lanes.
 __device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, const TapReq &q, SplatLds &lds) {
-    const unsigned long long any = __ballot(q.valid);
+    const unsigned long long any = ballot(q.valid);
     if (any == 0) return 0;
     const int lane = threadIdx.x & 63;
     const int big = 0x3fffffff;
@@ -697,7 +697,7 @@ __device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, 
         for (int tx = 0; tx < tiles_x; tx++) {
             const int tc = cmin + 8 * tx, tr = rmin + 8 * ty;
             const bool touch = q.valid && q.jj_ul <= tc + 7 && q.jj_ul + 1 >= tc && q.ii_ul <= tr + 7 && q.ii_ul + 1 >= tr;
-            unsigned long long rays = __ballot(touch);
+            unsigned long long rays = ballot(touch);
             if (rays == 0) continue;
             const int jj = tc + (lane & 7), ii = tr + (lane >> 3);
             const bool lands = tap_lands(ii, jj, W, H);

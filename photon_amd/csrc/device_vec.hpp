@@ -27,6 +27,9 @@ __device__ __forceinline__ bool isnan3(f3 v) { return isnan(v.x) || isnan(v.y) |
 __device__ __forceinline__ float nanf32() { return __int_as_float(0x7fc00000); }
 __device__ __forceinline__ f3 nan3() { const float n = nanf32(); return mk3(n, n, n); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// Lane mask of a predicate.  The builtin takes the i1 itself; HIP's __ballot(int) widens the predicate to an int and
+// compares it with zero again -- a v_cndmask + v_cmp pair per call that the march loops issue several times per sample.
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // 3x3 row-major matrix times vector, each row a left-to-right dot product
 __device__ __forceinline__ f3 matvec(const float *m, f3 v) {

@@ -32,12 +32,19 @@ __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(
 __device__ __forceinline__ f4 lerp4(f4 a, f4 b, float t) {
     return f4{lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)};
 }
+// lerp4 with the difference d = b - a already formed (the coherent trilinear tile parks it): fmaf(t, d, a), the same bits
+__device__ __forceinline__ f4 lerp4d(f4 a, f4 d, float t) {
+    return f4{fmaf(t, d.x, a.x), fmaf(t, d.y, a.y), fmaf(t, d.z, a.z), fmaf(t, d.w, a.w)};
+}
 // CUDA's linear texture filter keeps the interpolation weights in 9-bit fixed point with 8 fractional bits
 // (CUDA C Programming Guide, "Linear Filtering"): that is the arithmetic the reference's tex3D() calls run
 // with on its own hardware.  weight_scale = 256 reproduces it (round to nearest), 0 keeps exact f32 weights.
 // scale = 2^bits: the division is an exact multiplication by 2^-bits (no f32 divide sequence in the sampler)
+// floorf(a * scale + 0.5f) is written as floorf(fmaf(a, scale, 0.5f)): a * 2^bits is exact (a in [0, 1), no
+// overflow; a denormal scales exactly too), so the fused form rounds once exactly where the two-step form does --
+// the same bits as the CPU checker's two-step form, one instruction fewer per weight.
 __device__ __forceinline__ float quant_weight(float a, float scale, float inv) {
-    return scale > 0.f ? floorf(a * scale + 0.5f) * inv : a;
+    return scale > 0.f ? floorf(fmaf(a, scale, 0.5f)) * inv : a;
 }
 __device__ __forceinline__ f4 ldtexel(const f4 *p) {
     const float4 v = *reinterpret_cast<const float4 *>(p);      // one global_load_dwordx4

@@ -90,14 +90,40 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     return acc;
 }
 
+// Lane predicates of the march are kept as WAVE MASKS (64-bit, wave-uniform, SGPR pairs): a mask comes out of
+// ballot(one comparison) -- a single v_cmp writing an SGPR pair -- and masks combine with integer & | ~ on the scalar
+// unit.  A predicate that is an AND / OR of i1 values reaches ballot() as a 0/1 VGPR instead (v_cndmask + v_cmp per use),
+// and through nested branches it drags copies of the ray state along: rounds 1-2's form, ~45 VALU instructions per sample.
+// lane_of() turns a mask back into this lane's predicate where the code really is per lane (commits, rare paths).
+__device__ __forceinline__ bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 // What is parked in the wave's LDS area (wave-uniform, kept by the marchers across samples): consecutive
 // samples of a ray advance by half a texel, so about every other sample finds its block / brick still there
-// and skips the fetch.
-struct Parked { int tile; int brick; };
+// and skips the fetch.  A block is named by the BIT PATTERNS of its three floor() values (readlane'd from its
+// leader): comparing those needs no float -> int conversion on the per-sample path.
+struct Parked { int ti, tj, tk; int bi, bj, bk; };
+__device__ __forceinline__ Parked parked_none() {                // 0x7fffffff: a NaN pattern no floor() of a sampled coordinate has
+    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+}
 
-// Must be called by ALL 64 lanes of the wave (wave-uniform control flow); `need` says whether this
-// lane wants a sample.  blk = this wave's LDS area: a 64-texel tile followed by a 256-texel brick.
-__device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
+// Block coherence of a wave's sample: the first sampling lane leads; the wave is coherent when every sampling lane
+// wants the leader's block.  The floor values are compared as bit patterns (each integer-valued float has one pattern;
+// +0 is the only zero a floor of x - 0.5 produces): three v_readlane and three integer compares per sample, the rest on
+// the scalar unit.
+struct Lead { int i, j, k; };                                   // float bit patterns, wave-uniform (SGPRs)
+__device__ __forceinline__ Lead lead_of(unsigned long long todo, float fi, float fj, float fk) {
+    const int leader = __ffsll((long long)todo) - 1;
+    return Lead{__builtin_amdgcn_readlane(__float_as_int(fi), leader), __builtin_amdgcn_readlane(__float_as_int(fj), leader),
+                __builtin_amdgcn_readlane(__float_as_int(fk), leader)};
+}
+__device__ __forceinline__ unsigned long long same_block(const Lead &c, float fi, float fj, float fk) {
+    return ballot(__float_as_int(fi) == c.i) & ballot(__float_as_int(fj) == c.j) & ballot(__float_as_int(fk) == c.k);
+}
+
+// Must be called by ALL 64 lanes of the wave (wave-uniform control flow); `need` = mask of the lanes that want a
+// sample (the value returned to the other lanes is unspecified).  blk = this wave's LDS area: a 64-texel tile followed
+// by a 256-texel brick.
+__device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need,
                                                float x, float y, float z, Parked &parked) {
     f4 *const brick = blk + 64;                                 // the wave's 8x8x4 brick follows its 4x4x4 tile
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
@@ -106,34 +132,27 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     bspline_weights(xg - fi, wx[0], wx[1], wx[2], wx[3]);
     bspline_weights(yg - fj, wy[0], wy[1], wy[2], wy[3]);
     bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
-    const int bi = (int)fi, bj = (int)fj, bk = (int)fk;         // lanes that do not sample never lead and never match
     const int lane = threadIdx.x & 63;
-    f4 acc = f4{0, 0, 0, 0};
-    bool done = !need;
-    unsigned long long todo = __ballot(!done);
-    if (todo == 0) return acc;                                  // wave-uniform
+    if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
     {
         // COHERENT wave -- every sampling lane wants the block of the first one (BOS: always, except where a
         // wave straddles two sources or a cone straddles a texel boundary): one load instruction for the
         // whole 4x4x4 block, lane l <-> texel (l&3, (l>>2)&3, l>>4), clamp-to-edge per texel, parked in the
-        // tile; then the chain with broadcast reads.
-        const int leader = __ffsll((long long)todo) - 1;
-        const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
-                  ck = __builtin_amdgcn_readlane(bk, leader);
-        const bool mine = !done && bi == ci && bj == cj && bk == ck;
-        if (__ballot(mine) == todo) {                           // wave-uniform
-            // block id: base texels lie in [-1, n) per axis, so (c+1) fits n+1 values per axis
-            const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-            if (!PHOTON_TILE_REUSE || key != parked.tile) {     // wave-uniform (SALU compare)
+        // tile; then the chain with broadcast reads -- on every lane, unpredicated: a lane that does not sample reads
+        // the same (valid) tile and produces a value nobody uses.
+        const Lead c = lead_of(need, fi, fj, fk);
+        if ((same_block(c, fi, fj, fk) & need) == need) {       // wave-uniform
+            if (!PHOTON_TILE_REUSE || c.i != parked.ti || c.j != parked.tj || c.k != parked.tk) {     // wave-uniform (SALU compares)
+                const int ci = (int)__int_as_float(c.i), cj = (int)__int_as_float(c.j), ck = (int)__int_as_float(c.k);
                 const int tx = clampi(ci - 1 + (lane & 3), 0, v.nx - 1), ty = clampi(cj - 1 + ((lane >> 2) & 3), 0, v.ny - 1),
                           tz = clampi(ck - 1 + (lane >> 4), 0, v.nz - 1);
                 const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));      // < 2^31 texels (checked on the host)
                 __builtin_amdgcn_wave_barrier();
                 *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
                 __builtin_amdgcn_wave_barrier();
-                parked.tile = key;
+                parked.ti = c.i; parked.tj = c.j; parked.tk = c.k;
             }
-            if (mine) acc = cubic_taps_lds<4, 16>(blk, wx, wy, wz);
+            const f4 acc = cubic_taps_lds<4, 16>(blk, wx, wy, wz);
             __builtin_amdgcn_wave_barrier();
             return acc;
         }
@@ -143,6 +162,10 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     // Instead: park the 8x8x4 BRICK around the first unserved lane's block -- four loads per lane -- and let
     // every lane whose block lies within +-2 texels of it in x and y (same z) run its chain from there in ONE
     // pass, each lane reading its own addresses.  Same chain, same order, same bits.
+    const int bi = (int)fi, bj = (int)fj, bk = (int)fk;         // lanes that do not sample never lead and never match
+    f4 acc = f4{0, 0, 0, 0};
+    bool done = !lane_of(need);
+    unsigned long long todo = need;
 #pragma unroll 1
     for (int pass = 0; pass < PHOTON_BRICK_PASSES && todo != 0; pass++) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -150,8 +173,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                   ck = __builtin_amdgcn_readlane(bk, leader);
         const int di = bi - ci + 2, dj = bj - cj + 2;
         const bool in_brick = !done && bk == ck && (unsigned)di <= 4u && (unsigned)dj <= 4u;
-        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-        if (!PHOTON_TILE_REUSE || key != parked.brick) {        // wave-uniform
+        if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -162,14 +184,14 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                 *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
             }
             __builtin_amdgcn_wave_barrier();
-            parked.brick = key;
+            parked.bi = ci; parked.bj = cj; parked.bk = ck;
         }
         if (in_brick) {
             acc = cubic_taps_lds<8, 64>(brick + (dj * 8 + di), wx, wy, wz);
             done = true;
         }
         __builtin_amdgcn_wave_barrier();
-        todo = __ballot(!done);
+        todo = ballot(!done);
     }
     if (!done) acc = cubic_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);                       // stragglers
     return acc;
@@ -186,54 +208,65 @@ __device__ __attribute__((noinline)) f4 linear_gather_fn(const f4 *__restrict__ 
                              quant_weight(yb - fj, weight_scale, weight_inv), quant_weight(zb - fk, weight_scale, weight_inv));
 }
 
-__device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need,
+// v of the neighbouring lane of the pair (lane ^ 1): one DPP move, no LDS round trip
+__device__ __forceinline__ float pair_swap(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false));
+}
+
+// QUANT: the volume uses the texture unit's fixed-point weights (v.weight_scale > 0; the march kernels branch ONCE on
+// it -- as a run-time select per weight it cost three v_cndmask per sample).
+template <bool QUANT>
+__device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need,
                                                 float x, float y, float z, Parked &parked) {
     f4 *const brick = blk + 64;                                 // 8x8x2 texels around the leader for incoherent waves
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
     float a = xb - fi, b = yb - fj, c = zb - fk;
-    if (v.weight_scale > 0.f) {                                  // wave-uniform: texture-unit weights (8 fractional bits)
-        a = quant_weight(a, v.weight_scale, v.weight_inv); b = quant_weight(b, v.weight_scale, v.weight_inv);
-        c = quant_weight(c, v.weight_scale, v.weight_inv);
+    if (QUANT) {                                                // texture-unit weights (8 fractional bits)
+        a = floorf(fmaf(a, v.weight_scale, 0.5f)) * v.weight_inv;       // quant_weight() with the scale known positive
+        b = floorf(fmaf(b, v.weight_scale, 0.5f)) * v.weight_inv;
+        c = floorf(fmaf(c, v.weight_scale, 0.5f)) * v.weight_inv;
     }
-    const int bi = need ? (int)fi : 0, bj = need ? (int)fj : 0, bk = need ? (int)fk : 0;
     const int lane = threadIdx.x & 63;
-    f4 acc = f4{0, 0, 0, 0};
-    bool done = !need;
-    unsigned long long todo = __ballot(!done);
-    if (todo == 0) return acc;                                  // wave-uniform
+    if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
     {
-        // coherent wave: the 2x2x2 block of the first sampling lane serves everybody (lanes 0-7 fetch it)
-        const int leader = __ffsll((long long)todo) - 1;
-        const int ci = __builtin_amdgcn_readlane(bi, leader), cj = __builtin_amdgcn_readlane(bj, leader),
-                  ck = __builtin_amdgcn_readlane(bk, leader);
-        const bool mine = !done && bi == ci && bj == cj && bk == ck;
-        if (__ballot(mine) == todo) {                           // wave-uniform
-            const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-            if (!PHOTON_TILE_REUSE || key != parked.tile) {     // wave-uniform: the block is not parked yet
-                const int tx = clampi(ci + (lane & 1), 0, v.nx - 1), ty = clampi(cj + ((lane >> 1) & 1), 0, v.ny - 1),
-                          tz = clampi(ck + ((lane >> 2) & 1), 0, v.nz - 1);
+        // coherent wave: the 2x2x2 block of the first sampling lane serves everybody.  Lanes 0-7 fetch it and park it
+        // as four (texel, x-difference) pairs: slot 2p = texel (0,b,c), slot 2p+1 = texel (1,b,c) - texel (0,b,c) --
+        // the subtraction every lane's first-level lerp fmaf(a, t1 - t0, t0) would repeat on identical operands is done
+        // once per block by the fetching lane (same f32 operation, same bits; 16 VALU instructions fewer per sample).
+        // The blend runs on every lane, unpredicated (see tex3d_cubic_coop).
+        const Lead ld = lead_of(need, fi, fj, fk);
+        if ((same_block(ld, fi, fj, fk) & need) == need) {      // wave-uniform
+            if (!PHOTON_TILE_REUSE || ld.i != parked.ti || ld.j != parked.tj || ld.k != parked.tk) {  // wave-uniform: not parked yet
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 8) {
+                    const int ci = (int)__int_as_float(ld.i), cj = (int)__int_as_float(ld.j), ck = (int)__int_as_float(ld.k);
+                    const int tx = clampi(ci + (lane & 1), 0, v.nx - 1), ty = clampi(cj + ((lane >> 1) & 1), 0, v.ny - 1),
+                              tz = clampi(ck + ((lane >> 2) & 1), 0, v.nz - 1);
                     const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-                    *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
+                    const f4 o = f4{pair_swap(t.x), pair_swap(t.y), pair_swap(t.z), pair_swap(t.w)};     // the pair's other texel
+                    const bool hi = (lane & 1) != 0;
+                    *reinterpret_cast<float4 *>(blk + lane) = make_float4(hi ? t.x - o.x : t.x, hi ? t.y - o.y : t.y,
+                                                                          hi ? t.z - o.z : t.z, hi ? t.w - o.w : t.w);
                 }
                 __builtin_amdgcn_wave_barrier();
-                parked.tile = key;
+                parked.ti = ld.i; parked.tj = ld.j; parked.tk = ld.k;
             }
-            if (mine) {
-                // blk[tc*4 + tb*2 + ta]; same lerp tree as tex3d_linear
-                const f4 c00 = lerp4(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4(ldtexel(blk + 2), ldtexel(blk + 3), a);
-                const f4 c01 = lerp4(ldtexel(blk + 4), ldtexel(blk + 5), a), c11 = lerp4(ldtexel(blk + 6), ldtexel(blk + 7), a);
-                const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
-                acc = lerp4(c0, c1, c);
-            }
+            // blk[tc*4 + tb*2 + {0: texel, 1: x-difference}]; same lerp tree as tex3d_linear
+            const f4 c00 = lerp4d(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4d(ldtexel(blk + 2), ldtexel(blk + 3), a);
+            const f4 c01 = lerp4d(ldtexel(blk + 4), ldtexel(blk + 5), a), c11 = lerp4d(ldtexel(blk + 6), ldtexel(blk + 7), a);
+            const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
+            const f4 acc = lerp4(c0, c1, c);
             __builtin_amdgcn_wave_barrier();
             return acc;
         }
     }
     // incoherent wave: bricks of 8x8x2 texels around the first unserved lane (two loads per lane); every lane
     // whose block starts within [-3, +3] texels of it in x and y (same z) blends from there in one pass
+    const int bi = (int)fi, bj = (int)fj, bk = (int)fk;
+    f4 acc = f4{0, 0, 0, 0};
+    bool done = !lane_of(need);
+    unsigned long long todo = need;
 #pragma unroll 1
     for (int pass = 0; pass < PHOTON_BRICK_PASSES && todo != 0; pass++) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -241,8 +274,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                   ck = __builtin_amdgcn_readlane(bk, leader);
         const int di = bi - ci + 3, dj = bj - cj + 3;
         const bool in_brick = !done && bk == ck && (unsigned)di <= 6u && (unsigned)dj <= 6u;
-        const int key = ((ck + 1) * (v.ny + 1) + (cj + 1)) * (v.nx + 1) + (ci + 1);
-        if (!PHOTON_TILE_REUSE || key != parked.brick) {        // wave-uniform
+        if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 2; j++) {
@@ -253,7 +285,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                 *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
             }
             __builtin_amdgcn_wave_barrier();
-            parked.brick = key;
+            parked.bi = ci; parked.bj = cj; parked.bk = ck;
         }
         if (in_brick) {
             const f4 *q = brick + (dj * 8 + di);
@@ -264,7 +296,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
             done = true;
         }
         __builtin_amdgcn_wave_barrier();
-        todo = __ballot(!done);
+        todo = ballot(!done);
     }
     if (!done) acc = linear_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z, v.weight_scale, v.weight_inv);
     return acc;
@@ -309,55 +341,52 @@ __device__ __forceinline__ f3 lookup_index_u(f3 pos, const MarchU &u) {
     const f3 fn = mk3(u.sx * off.x, u.sy * off.y, u.sz * off.z);
     return mk3(1 + fn.x * u.nxm2, 1 + fn.y * u.nym2, 1 + fn.z * u.nzm2);
 }
-__device__ __forceinline__ bool can_access_u(const MarchU &u, f3 l) {
-    return !(l.x < 0 || l.y < 0 || l.z < 0 || l.x >= u.fnx || l.y >= u.fny || l.z >= u.fnz);
+// lanes whose lookup index can be sampled (.h:253-277)
+__device__ __forceinline__ unsigned long long access_mask(const MarchU &u, f3 l) {
+    return ~(ballot(l.x < 0) | ballot(l.y < 0) | ballot(l.z < 0) | ballot(l.x >= u.fnx) | ballot(l.y >= u.fny) | ballot(l.z >= u.fnz));
 }
-// The reference's second test (0 <= lookup < n, .h:236-248) cannot fail once the first has passed:
-// min <= p < max puts (p - min) * scale in [0, 1 + 2^-23], so lookup = 1 + that * (n - 2) lies in
-// [1, n - 1 + (n - 2) * 2^-23] -- inside [0, n) for every n the samplers accept; a NaN position passes
-// both tests alike.  (The CPU oracle evaluates both.)
-__device__ __forceinline__ bool inside_box_u(f3 p, const MarchU &u, f3) {
-    return !(p.x < u.minx || p.y < u.miny || p.z < u.minz || p.x >= u.maxx || p.y >= u.maxy || p.z >= u.maxz);
+// Lanes inside the box, min <= p < max (.h:217-251; a NaN position passes, as it does in the reference: every
+// comparison is false).  The reference's second test (0 <= lookup < n, .h:236-248) cannot fail once the first has passed:
+// (p - min) * scale lies in [0, 1 + 2^-23], so lookup = 1 + that * (n - 2) lies in [1, n - 1 + (n - 2) * 2^-23] --
+// inside [0, n) for every n the samplers accept.  (The CPU oracle evaluates both.)  For the same reason
+// access_refractive_index -- that very test -- can only fail for a ray that is NOT inside: the march evaluates it only for
+// rays on their first iteration, whose inside test the reference skips (loop_ctr != 0, .h:1021).
+__device__ __forceinline__ unsigned long long inside_mask(f3 p, const MarchU &u) {
+    return ~(ballot(p.x < u.minx) | ballot(p.y < u.miny) | ballot(p.z < u.minz) | ballot(p.x >= u.maxx) | ballot(p.y >= u.maxy) | ballot(p.z >= u.maxz));
 }
 
 // Statistics.  MarchCount (device_volume.hpp) counts per lane -- photon_trace_volume_rays reports
 // the steps of each ray.  The render kernels only need totals: WaveCount keeps them wave-uniform (SALU
-// popcount of the ballot, SGPR accumulators), which takes two VGPRs and two VALU adds per sample out
-// of the hot loop.  Must be called at wave-uniform points.
+// popcount of the lane mask, SGPR accumulators): no VGPR, no VALU instruction in the hot loop.
 struct WaveCount { unsigned iterations; unsigned samples; };
-__device__ __forceinline__ void count_samples(MarchCount &mc, bool yes) { if (yes) mc.samples++; }
-__device__ __forceinline__ void count_iterations(MarchCount &mc, bool yes) { if (yes) mc.iterations++; }
-__device__ __forceinline__ void count_samples(WaveCount &mc, bool yes) { mc.samples += (unsigned)__popcll(__ballot(yes)); }
-__device__ __forceinline__ void count_iterations(WaveCount &mc, bool yes) { mc.iterations += (unsigned)__popcll(__ballot(yes)); }
+__device__ __forceinline__ void count_samples(MarchCount &mc, unsigned long long m) { if (lane_of(m)) mc.samples++; }
+__device__ __forceinline__ void count_iterations(MarchCount &mc, unsigned long long m) { if (lane_of(m)) mc.iterations++; }
+__device__ __forceinline__ void count_samples(WaveCount &mc, unsigned long long m) { mc.samples += (unsigned)__popcll(m); }
+__device__ __forceinline__ void count_iterations(WaveCount &mc, unsigned long long m) { mc.iterations += (unsigned)__popcll(m); }
 
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
-template <int INTERP, class CNT>
-__device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, bool need, f3 lookup,
-                                          const f4 &val_prev, CNT &mc, Parked &parked) {
-    f4 val = INTERP == 1 ? tex3d_linear_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked)
+template <int INTERP, bool QUANT, class CNT>
+__device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need, f3 lookup,
+                                          const f4 &val_prev, float data_min, CNT &mc, Parked &parked) {
+    f4 val = INTERP == 1 ? tex3d_linear_coop<QUANT>(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked)
                          : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked);
     count_samples(mc, need);
     if (INTERP == 1) {
-        const float ambient = 1.000277;
-        const bool low = need && val.w < v.data_min;
-        const bool repair = low && val_prev.w == 0;
-        if (__ballot(repair) != 0) {                            // wave-uniform, rare
-            const f4 t = tex3d_linear_coop(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
-            count_samples(mc, repair);
-            if (repair) val = f4{t.x, t.y, t.z, ambient - 1};
+        const unsigned long long low = need & ballot(val.w < data_min);
+        if (low != 0) {                                         // wave-uniform, rare: a blend below the volume's minimum
+            const float ambient = 1.000277;
+            const unsigned long long repair = low & ballot(val_prev.w == 0);
+            if (repair != 0) {
+                const f4 t = tex3d_linear_coop<QUANT>(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
+                count_samples(mc, repair);
+                if (lane_of(repair)) val = f4{t.x, t.y, t.z, ambient - 1};
+            }
+            if (lane_of(low & ~repair)) val = val_prev;
         }
-        if (low && !repair) val = val_prev;
     }
     return val;
 }
 
-// Wave-synchronous RK4 (reference: trace_rays_through_density_gradients.h:952-1291).  All 64
-// lanes call it; `active` = this lane carries a ray that is inside (or entering) the volume.  One
-// trip of the loop is one RK4 iteration: Sharma's three samples A, B, C in straight-line code with
-// a cooperative sampler call each.  A lane whose ray leaves the box is predicated off (the
-// reference's `break`); a lane that has to step forward without sampling (the reference's
-// `continue`) sits out the rest of the trip and retries on the next one.  The per-ray operation
-// order is that of rk4<> in device_volume.hpp.
 // Intermediate ray dumps (save_intermediate_ray_data): position / direction at the start of each
 // of the first `slots` iterations, [ray][slot] float3, world frame.  Like the reference only the
 // trilinear branches record them (.h:784-790, 1004-1008); unlike it the ray index is bounds-checked
@@ -371,155 +400,171 @@ __device__ __forceinline__ void record_intermediate(const InterDump &d, int loop
     }
 }
 
-template <int INTERP, bool SAVE, class CNT>
-__device__ __forceinline__ void rk4_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
+// Wave-synchronous RK4 (reference: trace_rays_through_density_gradients.h:952-1291).  All 64
+// lanes call it; active_lane = this lane carries a ray that is inside (or entering) the volume.  One
+// trip of the loop is one RK4 iteration: Sharma's three samples A, B, C in straight-line code with
+// a cooperative sampler call each.  A lane whose ray leaves the box drops out of `active` (the
+// reference's `break`); a lane that has to step forward without sampling (the reference's
+// `continue`) sits out the rest of the trip and retries on the next one.  The per-ray operation
+// order is that of rk4<> in device_volume.hpp.
+//
+// Shape of the code (round 3): the stage algebra runs UNPREDICATED on every lane -- a lane that does not take part
+// computes garbage nobody reads -- and the predicates (active, go, spin, first) are wave masks; only the commit of a
+// finished iteration and the rare paths are predicated.
+template <int INTERP, bool SAVE, bool QUANT, class CNT>
+__device__ __forceinline__ void rk4_coop(bool active_lane, f3 &rpos, f3 &rdir, const VolumeDev &v,
                                          const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
                                          const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0;
-    Parked parked{-1, -1};
+    unsigned trips = 0;                                         // wave-uniform; no lane's loop_ctr exceeds it
+    Parked parked = parked_none();
+    // val_prev: the last value a lane sampled (n-1 form), for the linear branch's repair.  Updated unpredicated; the
+    // only live lanes that sit samples out are spinning ones, which have not sampled yet (a ray spins only on its first
+    // iteration, see inside_mask) -- theirs is put back to its initial zeros at the end of such a trip.
     f4 val_prev = f4{0, 0, 0, 0};
-    f3 T_n = rdir, A = mk3(0, 0, 0), B = mk3(0, 0, 0), spos = rpos;     // only meaningful while `go`
-    float delta_t = 0.f, current_n = 1.f;
-    while (__ballot(active) != 0) {                             // wave-uniform loop
+    unsigned long long active = ballot(active_lane);
+    unsigned long long first = active;                          // lanes with loop_ctr == 0
+    while (active != 0) {                                       // wave-uniform loop
         // ---------------- sample A at R_n (= rpos) ----------------
-        bool need = false;
-        f3 lookup = mk3(0, 0, 0);
-        if (active) {
-            if (loop_ctr > kLoopMax) {
-                active = false;
-            } else {
-                if (SAVE && INTERP == 1) record_intermediate(idump, loop_ctr, rpos, rdir);
-                lookup = lookup_index_u(rpos, u);
-                if (!inside_box_u(rpos, u, lookup) && loop_ctr != 0) {
-                    active = false;                             // left the volume: done
-                } else if (!can_access_u(u, lookup)) {          // .h:1043-1049
-                    rpos = rpos + u.spin_step * rdir;
-                    if (++spins > kSpinMax) active = false;
-                } else {
-                    need = true;
-                }
-            }
+        f3 lookup = lookup_index_u(rpos, u);
+        const unsigned long long in_a = inside_mask(rpos, u);
+        unsigned long long not_over = ~0ull;
+        if (trips > (unsigned)kLoopMax) not_over = ~ballot(loop_ctr > kLoopMax);       // wave-uniform; a safety cap, never reached
+        trips++;
+        if (SAVE && INTERP == 1) { if (lane_of(active & not_over)) record_intermediate(idump, loop_ctr, rpos, rdir); }
+        const unsigned long long alive = active & not_over & (in_a | first);           // else the reference's `break`
+        unsigned long long go = alive, spin = 0;                // go: lane samples A and -- if that succeeds -- B and C
+        if ((alive & ~in_a) != 0) {                             // wave-uniform: rays that start outside the box (.h:1043-1049)
+            const unsigned long long access = access_mask(u, lookup);
+            go = alive & access;
+            spin = alive & ~access;                             // the reference's `continue`: step forward, retry next trip
         }
-        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
-        bool go = false;                                        // lane continues to samples B and C
-        if (need) {
-            if (INTERP == 2 && val.w < u.data_min) {            // .h:1220-1227
+        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        if (INTERP == 2) {                                      // .h:1220-1227
+            const unsigned long long low = go & ballot(val.w < u.data_min);
+            spin |= low;
+            go &= ~low;
+        }
+        active = alive;
+        first &= ~go;
+        if (spin != 0) {                                        // wave-uniform, rare
+            if (lane_of(spin)) {
                 rpos = rpos + u.spin_step * rdir;
-                if (++spins > kSpinMax) active = false;
-            } else {
-                loop_ctr += 1;
-                val.w += 1;
-                current_n = val.w;
-                delta_t = u.step / val.w;
-                T_n = val.w * rdir;
-                A = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
-                spos = rpos + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;      // .h:1088
-                if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
-                go = true;
+                spins++;
             }
+            active &= ~(spin & ballot(spins > kSpinMax));
         }
+        loop_ctr += lane_of(go) ? 1 : 0;
+        const float n_a = val.w + 1;
+        const float delta_t = u.step / n_a;
+        f3 T_n = n_a * rdir;
+        const f3 A = delta_t * mk3(n_a * val.x, n_a * val.y, n_a * val.z);
+        f3 spos = rpos + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;       // .h:1088
+        if (INTERP == 1) val_prev = f4{val.x, val.y, val.z, n_a - 1};
         // ---------------- sample B ----------------
-        need = false;
-        if (go) {
-            lookup = lookup_index_u(spos, u);
-            if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1094-1101
-            else need = true;
-        }
-        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
-        if (need) {
-            val.w += 1;
-            B = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
-            spos = rpos + delta_t * T_n + (0.5f * delta_t) * B;                     // .h:1131
-            if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
-        }
+        lookup = lookup_index_u(spos, u);
+        unsigned long long in = inside_mask(spos, u);           // .h:1094-1101: outside = `break`, nothing committed
+        active &= ~go | in;
+        go &= in;
+        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        const float n_b = val.w + 1;
+        const f3 B = delta_t * mk3(n_b * val.x, n_b * val.y, n_b * val.z);
+        spos = rpos + delta_t * T_n + (0.5f * delta_t) * B;                     // .h:1131
+        if (INTERP == 1) val_prev = f4{val.x, val.y, val.z, n_b - 1};
         // ---------------- sample C ----------------
-        need = false;
-        if (go) {
-            lookup = lookup_index_u(spos, u);
-            if (!inside_box_u(spos, u, lookup)) { active = false; go = false; }     // .h:1135-1141
-            else need = true;
+        lookup = lookup_index_u(spos, u);
+        in = inside_mask(spos, u);                              // .h:1135-1141
+        active &= ~go | in;
+        go &= in;
+        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        const float n_c = val.w + 1;
+        const f3 C = delta_t * mk3(n_c * val.x, n_c * val.y, n_c * val.z);
+        if (INTERP == 1) val_prev = f4{val.x, val.y, val.z, n_c - 1};
+        if (lane_of(go)) {                                      // the iteration completed: commit
+            rpos = rpos + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));         // .h:1169
+            T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);                         // .h:1170
+            rdir = normalize(T_n / (INTERP == 1 ? n_a : n_c));                         // .h:1178 / 1276
         }
-        val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
-        if (need) {
-            val.w += 1;
-            const f3 C = delta_t * mk3(val.w * val.x, val.w * val.y, val.w * val.z);
-            rpos = rpos + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));      // .h:1169
-            T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);                      // .h:1170
-            rdir = normalize(T_n / (INTERP == 1 ? current_n : val.w));              // .h:1178 / 1276
-            if (INTERP == 1) { val_prev = val; val_prev.w -= 1; }
-        }
-        count_iterations(mc, need);
+        count_iterations(mc, go);
+        if (INTERP == 1 && spin != 0) { if (lane_of(spin)) val_prev = f4{0, 0, 0, 0}; }
     }
 }
 
-// Wave-synchronous Euler integrator (reference: .h:743-950, noise hook not built): one
-// cooperative sample per trip.  Per-ray operation order is that of euler<> in device_volume.hpp.
-// Gradient noise of the Euler integrator (.h:853-863): N(0,1)*sigma added to dn/dx, dn/dy.
+// Wave-synchronous Euler integrator (reference: .h:743-950): one cooperative sample per trip.  Per-ray operation
+// order is that of euler<> in device_volume.hpp.
+// Gradient noise of the Euler integrator (.h:853-863): N(0,1)*sigma added to dn/dx, dn/dy.  NOISE is a template
+// parameter: with the Philox generator behind a run-time flag the default instantiation spilled 38 VGPRs into its loop.
 struct GradNoise { int on; float std; unsigned long long seed, ray_id; };
 
-
-template <int INTERP, bool SAVE, class CNT>
-__device__ __forceinline__ void euler_coop(bool active, f3 &rpos, f3 &rdir, const VolumeDev &v,
+template <int INTERP, bool SAVE, bool NOISE, bool QUANT, class CNT>
+__device__ __forceinline__ void euler_coop(bool active_lane, f3 &rpos, f3 &rdir, const VolumeDev &v,
                                            const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
                                            const GradNoise &gn, const InterDump &idump) {
     const MarchU u = make_march_consts(v, scale);
     int loop_ctr = 0, spins = 0;
-    Parked parked{-1, -1};
+    unsigned trips = 0;
+    Parked parked = parked_none();
     f4 val_prev = f4{0, 0, 0, 0};
-    while (__ballot(active) != 0) {
-        bool need = false;
-        f3 lookup = mk3(0, 0, 0);
-        if (active) {
-            if (loop_ctr > kLoopMax) {
-                active = false;
-            } else {
-                if (SAVE && INTERP == 1) record_intermediate(idump, loop_ctr, rpos, rdir);
-                lookup = lookup_index_u(rpos, u);
-                if (!inside_box_u(rpos, u, lookup) && loop_ctr != 0) {
-                    active = false;
-                } else if (INTERP == 1 && !can_access_u(u, lookup)) {   // only the linear branch guards (.h:821)
-                    rpos = rpos + u.spin_step * rdir;
-                    if (++spins > kSpinMax) active = false;
-                } else {
-                    need = true;
-                }
-            }
+    unsigned long long active = ballot(active_lane);
+    unsigned long long first = active;
+    while (active != 0) {
+        const f3 lookup = lookup_index_u(rpos, u);
+        const unsigned long long in_a = inside_mask(rpos, u);
+        unsigned long long not_over = ~0ull;
+        if (trips > (unsigned)kLoopMax) not_over = ~ballot(loop_ctr > kLoopMax);
+        trips++;
+        if (SAVE && INTERP == 1) { if (lane_of(active & not_over)) record_intermediate(idump, loop_ctr, rpos, rdir); }
+        const unsigned long long alive = active & not_over & (in_a | first);
+        unsigned long long go = alive, spin = 0;
+        if (INTERP == 1 && (alive & ~in_a) != 0) {              // only the linear branch guards (.h:821)
+            const unsigned long long access = access_mask(u, lookup);
+            go = alive & access;
+            spin = alive & ~access;
         }
-        f4 val = sample_coop<INTERP, CNT>(v, tex, blk, need, lookup, val_prev, mc, parked);
-        bool stepped = false;
-        if (need) {
-            if (INTERP == 1) {
-                const float current_n = 1 + val.w;
-                if (gn.on) {
-                    float n0, n1;
-                    photon_normal2(gn.seed, gn.ray_id, (unsigned)loop_ctr, PHOTON_STREAM_NGRAD_NOISE, &n0, &n1);
-                    val.x += n0 * gn.std;
-                    val.y += n1 * gn.std;
-                }
-                rdir = rdir + u.step * mk3(val.x, val.y, val.z);       // .h:869 (not renormalised)
-                rpos = rpos + u.step / current_n * rdir;                // .h:875
-                val_prev = val;
-                loop_ctr += 1;
-                stepped = true;
-            } else if (val.w < u.data_min) {                            // .h:916-923
+        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        if (INTERP == 2) {                                      // .h:916-923
+            const unsigned long long low = go & ballot(val.w < u.data_min);
+            spin |= low;
+            go &= ~low;
+        }
+        active = alive;
+        first &= ~go;
+        if (spin != 0) {                                        // wave-uniform, rare
+            if (lane_of(spin)) {
                 rpos = rpos + u.spin_step * rdir;
-                if (++spins > kSpinMax) active = false;
-            } else {
-                loop_ctr += 1;
-                rdir = normalize(rdir + u.step * mk3(val.x, val.y, val.z));     // .h:931-933
+                spins++;
+            }
+            active &= ~(spin & ballot(spins > kSpinMax));
+        }
+        if (INTERP == 1) {
+            if (NOISE) {
+                float n0, n1;
+                photon_normal2(gn.seed, gn.ray_id, (unsigned)loop_ctr, PHOTON_STREAM_NGRAD_NOISE, &n0, &n1);
+                val.x += n0 * gn.std;
+                val.y += n1 * gn.std;
+            }
+            if (lane_of(go)) {
+                const float current_n = 1 + val.w;
+                rdir = rdir + u.step * mk3(val.x, val.y, val.z);               // .h:869 (not renormalised)
+                rpos = rpos + u.step / current_n * rdir;                       // .h:875
+                val_prev = val;
+            }
+        } else {
+            if (lane_of(go)) {
+                rdir = normalize(rdir + u.step * mk3(val.x, val.y, val.z));    // .h:931-933
                 const float n = 1 + val.w;
-                rpos = rpos + rdir * u.step / n;                        // .h:939
-                stepped = true;
+                rpos = rpos + rdir * u.step / n;                               // .h:939
             }
         }
-        count_iterations(mc, stepped);
+        loop_ctr += lane_of(go) ? 1 : 0;
+        count_iterations(mc, go);
     }
 }
 
 // trace_rays_through_density_gradients (.h:1455-1544), wave-synchronous.  has_ray = this lane
 // carries a ray at all (tail lanes of the last workgroup do not).
-template <int ALGO, int INTERP, bool SAVE, class CNT>
+template <int ALGO, int INTERP, bool SAVE, bool NOISE, bool QUANT, class CNT>
 __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &dir_io, const VolumeDev &v,
                                                   const f4 *__restrict__ tex, f4 *blk, CNT &mc,
                                                   const GradNoise &gn, const InterDump &idump) {
@@ -534,8 +579,8 @@ __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &
         }
         if (active) pos_io = pos;
     }
-    if (ALGO == 1) euler_coop<INTERP, SAVE, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump);
-    else rk4_coop<INTERP, SAVE, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump);
+    if (ALGO == 1) euler_coop<INTERP, SAVE, NOISE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump);
+    else rk4_coop<INTERP, SAVE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump);
 }
 
 }  // namespace photon

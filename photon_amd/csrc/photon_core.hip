@@ -108,7 +108,7 @@ struct DumpDev {                    // ray dumps (save_lightrays), indexed by ch
     int inter_slots;
 };
 
-enum { CNT_ON_SENSOR = 0, CNT_ITER = 1, CNT_SAMPLES = 2, CNT_TAPS = 3, CNT_MARCHED = 4, CNT_N = 5 };
+enum { CNT_ON_SENSOR = 0, CNT_ITER = 1, CNT_SAMPLES = 2, CNT_TAPS = 3, CNT_MARCHED = 4, CNT_CLK = 5, CNT_REAL = 6, CNT_N = 7 };
 // Statistics counters are kept in kCounterSlots copies (one 64-byte line each) and summed on the host: with one
 // copy every wave of a launch ends on an atomic to the SAME address, and 1.6e5 same-address device-scope atomics
 // serialise into ~2 ms -- more than the rest of the sensor stage (measured).
@@ -339,7 +339,10 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
     MarchCount mc{0, 0};
     const GradNoise no_noise{0, 0.f, 0ull, 0ull};
     const InterDump no_dump{nullptr, nullptr, 0, 0, 0u};
-    trace_volume_coop<ALGO, INTERP, false, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
+    if (INTERP == 1 && v.weight_scale > 0.f)                    // kernel-uniform: texture-unit weights
+        trace_volume_coop<ALGO, INTERP, false, false, true, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
+    else
+        trace_volume_coop<ALGO, INTERP, false, false, false, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
     if (has_ray) {
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
         dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
@@ -408,11 +411,21 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #ifndef PHOTON_MARCH_WAVES_LINEAR
 #define PHOTON_MARCH_WAVES_LINEAR 5     // a sixth wave (80 VGPRs) costs 20 spilled dwords in the RK4 loop: 27.7 vs 26.6 ms on C3 (r02)
 #endif
-template <int ALGO, int INTERP, bool SAVE>
+// Shader-clock stamp of a wave: s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
+// (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The chip lowers its clock under load, by an amount that differs from
+// device to device; the ratio of the two deltas, summed over the waves of a launch, is the clock the march actually ran
+// at -- what bench.py normalises its roofline fraction with.  Two stamps per wave (a wave lives ~2 ms): no cost.
+__device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned long long &real) {
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk), "=s"(real) : : "memory");
+}
+
+template <int ALGO, int INTERP, bool SAVE, bool NOISE>
 __global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters,
                                                        NoiseDev noise, unsigned long long ray_base, InterDump idump) {
     __shared__ f4 tiles[4][64 + 256];                           // per wave: 4x4x4 tile + 8x8x4 brick (device_volume_coop.hpp)
+    unsigned long long clk0, real0, clk1, real1;
+    clock_stamp(clk0, real0);
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned r = bid * blockDim.x + threadIdx.x;
     const bool has_ray = r < n_rays;
@@ -424,19 +437,27 @@ __global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOT
         d = mk3(st.dx[r], st.dy[r], st.dz[r]);
         marching = !isnan3(p);                                  // rays marked dead by raygen_kernel stay out of the march
     }
-    const unsigned n_marched = (unsigned)__popcll(__ballot(marching));     // rays that enter the march (not skipped as doomed)
+    const unsigned n_marched = (unsigned)__popcll(ballot(marching));       // rays that enter the march (not skipped as doomed)
     const GradNoise gn{noise.add_ngrad, noise.ngrad_std, noise.seed, ray_base + r};
     idump.ray = r;                                              // chunk-global ray id, like the final dumps
-    trace_volume_coop<ALGO, INTERP, SAVE, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
+    if (INTERP == 1 && vol.weight_scale > 0.f)                  // kernel-uniform: the texture unit's 8-bit weights (the default) / exact f32
+        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
+    else
+        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, false, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);
     if (marching) {
         st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
         st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
     }
+    clock_stamp(clk1, real1);
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *slot = counter_slot(counters);
         if (mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)mc.iterations);
         if (mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)mc.samples);
-        if (n_marched) atomicAdd(&slot[CNT_MARCHED], (unsigned long long)n_marched);
+        if (n_marched) {
+            atomicAdd(&slot[CNT_MARCHED], (unsigned long long)n_marched);
+            atomicAdd(&slot[CNT_CLK], clk1 - clk0);
+            atomicAdd(&slot[CNT_REAL], real1 - real0);
+        }
     }
 }
 
@@ -669,6 +690,15 @@ struct photon_scene {
     unsigned long long *d_counters = nullptr;
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // statistics window (photon_scene_stats_begin / _end): traces inside it record their events and leave the counters
+    // running instead of synchronising per call -- a timed loop then has no host sync and no D2H copy inside it
+    bool win_open = false;
+    std::vector<hipEvent_t> win_events;        // created on demand, reused by the next window
+    size_t win_used = 0;
+    std::vector<std::pair<size_t, size_t>> win_march, win_total;      // (begin, end) event indices
+    uint64_t win_rays = 0;
+    uint32_t win_traces = 0;
+    bool win_have_volume = false;
     int ray_order_mode = 2;             // 0 source-major, 1 lens-major, 2 auto (photon_scene_set_ray_order)
     bool skip_doomed = true;            // photon_scene_set_skip_doomed
     float lens_z = 0.f;                 // element 0's centre, for the auto rule
@@ -1078,6 +1108,7 @@ void photon_scene_free(photon_scene_t *s) {
     if (s->d_acc) (void)hipFree(s->d_acc);
     if (s->d_perm) (void)hipFree(s->d_perm);
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : s->win_events) if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -1472,7 +1503,7 @@ static float doom_margin(const photon_scene *s, const photon_volume *vol, int al
 }
 
 static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
-                        long long src_end, DumpDev dump, hipStream_t stream, bool timed) {
+                        long long src_end, DumpDev dump, hipStream_t stream, hipEvent_t ev_march_begin, hipEvent_t ev_march_end) {
     double *d_image = s->d_acc;
     const unsigned long long n64 = (unsigned long long)(src_end - src_begin) * (unsigned)s->dev.rays_per_source;
     if (n64 == 0) return 0;
@@ -1497,24 +1528,28 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         if (rc) return rc;
         hipLaunchKernelGGL(raygen_kernel, grid, block, 0, stream, s->dev, src_begin, n, s->ws);
         PH_CHECK(hipGetLastError());
-        if (timed) PH_CHECK(hipEventRecord(s->ev[1], stream));
+        if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
         const int interp = vol->dev.interpolation;
         const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
         const unsigned long long ray_base = (unsigned long long)(s->dev.source_base + src_begin) * (unsigned)s->dev.rays_per_source;
         const InterDump idump{dump.inter_pos, dump.inter_dir, dump.inter_slots, dump.num_save, 0u};
         const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
-#define PH_MARCH(A, I, S) hipLaunchKernelGGL((march_kernel<A, I, S>), grid, block, 0, stream, vol->dev, tex, n, s->ws, \
-                                             s->d_counters, s->dev.noise, ray_base, idump)
+#define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), grid, block, 0, stream, vol->dev, tex, n, s->ws, \
+                                                s->d_counters, s->dev.noise, ray_base, idump)
         if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm != 1 && algorithm != 2) hipLaunchKernelGGL((march_extra_kernel<0>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
-        else if (algorithm == 1 && interp == 1) { if (save) PH_MARCH(1, 1, true); else PH_MARCH(1, 1, false); }
-        else if (algorithm == 1) PH_MARCH(1, 2, false);
-        else if (interp == 1) { if (save) PH_MARCH(2, 1, true); else PH_MARCH(2, 1, false); }
-        else PH_MARCH(2, 2, false);
+        else if (algorithm == 1 && interp == 1) {              // the gradient-noise hook exists in this branch only (.h:853-863)
+            const bool ngrad = s->dev.noise.add_ngrad != 0;
+            if (save) { if (ngrad) PH_MARCH(1, 1, true, true); else PH_MARCH(1, 1, true, false); }
+            else { if (ngrad) PH_MARCH(1, 1, false, true); else PH_MARCH(1, 1, false, false); }
+        }
+        else if (algorithm == 1) PH_MARCH(1, 2, false, false);
+        else if (interp == 1) { if (save) PH_MARCH(2, 1, true, false); else PH_MARCH(2, 1, false, false); }
+        else PH_MARCH(2, 2, false, false);
 #undef PH_MARCH
         PH_CHECK(hipGetLastError());
-        if (timed) PH_CHECK(hipEventRecord(s->ev[2], stream));
+        if (ev_march_end) PH_CHECK(hipEventRecord(ev_march_end, stream));
         // erf splats: optics and splat as two kernels (each gets the register file to itself); the 4-pixel
         // splat is done in place by the first
         const bool erf = PHOTON_SPLIT_SENSOR && (s->dev.cam.implement_diffraction || s->dev.elems[0].element_type == 'n');
@@ -1535,11 +1570,23 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     return 0;
 }
 
+// An event of the open statistics window (created on first use, kept for the next window).
+static int window_event(photon_scene *s, size_t *index_out) {
+    if (s->win_used == s->win_events.size()) {
+        hipEvent_t e = nullptr;
+        PH_CHECK(hipEventCreate(&e));
+        s->win_events.push_back(e);
+    }
+    *index_out = s->win_used++;
+    return 0;
+}
+
 // The launch loop for sources [src_begin, src_end) into the scene's private f64 accumulator (zeroed first); the
 // caller folds the accumulator into an image (end_accumulate) -- or, when several devices share one call, sums the
-// accumulators first.
+// accumulators first.  timed: 0 no events; 1 immediate (the march of every launch is timed with ev[1], ev[2] and the host
+// waits for it: photon_trace with a stats pointer); 2 deferred (events of the open statistics window, no host wait).
 static int trace_accumulate(photon_scene *scene, const photon_volume *vol, int ray_tracing_algorithm, long long src_begin,
-                            long long src_end, hipStream_t stream, bool timed, float *march_ms_out) {
+                            long long src_end, hipStream_t stream, int timed, float *march_ms_out) {
     const unsigned rps = (unsigned)scene->dev.rays_per_source;
     if (rps > kMaxRaysPerLaunch) { fprintf(stderr, "photon: too many rays per source\n"); return 1; }
     const long long max_sources = std::max<long long>(1, kMaxRaysPerLaunch / rps);
@@ -1548,9 +1595,18 @@ static int trace_accumulate(photon_scene *scene, const photon_volume *vol, int r
     { const int rc = begin_accumulate(scene, stream); if (rc) return rc; }
     for (long long b = src_begin; b < src_end; b += max_sources) {
         const long long e = std::min<long long>(src_end, b + max_sources);
-        const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, no_dump, stream, timed);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed == 1 && vol) { e0 = scene->ev[1]; e1 = scene->ev[2]; }
+        if (timed == 2 && vol) {
+            size_t i0, i1;
+            { const int rc = window_event(scene, &i0); if (rc) return rc; }
+            { const int rc = window_event(scene, &i1); if (rc) return rc; }
+            e0 = scene->win_events[i0]; e1 = scene->win_events[i1];
+            scene->win_march.emplace_back(i0, i1);
+        }
+        const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, no_dump, stream, e0, e1);
         if (rc) return rc;
-        if (timed && vol) {
+        if (timed == 1 && vol) {
             PH_CHECK(hipEventSynchronize(scene->ev[2]));
             float ms = 0.f;
             PH_CHECK(hipEventElapsedTime(&ms, scene->ev[1], scene->ev[2]));
@@ -1558,6 +1614,23 @@ static int trace_accumulate(photon_scene *scene, const photon_volume *vol, int r
         }
     }
     if (march_ms_out) *march_ms_out = march_ms;
+    return 0;
+}
+
+// Sum the counter slots into stats (the caller has made sure the device is done with them).
+static int read_counters(photon_scene *scene, bool have_volume, photon_trace_stats_t *stats) {
+    std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
+    PH_CHECK(hipMemcpy(slots.data(), scene->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long c[CNT_N] = {};
+    for (int k = 0; k < kCounterSlots; k++)
+        for (int j = 0; j < CNT_N; j++) c[j] += slots[(size_t)k * kCounterStride + j];
+    stats->rays_on_sensor = c[CNT_ON_SENSOR];
+    stats->rk_iterations = c[CNT_ITER];
+    stats->volume_samples = c[CNT_SAMPLES];
+    stats->sensor_taps = c[CNT_TAPS];
+    stats->rays_marched = have_volume ? c[CNT_MARCHED] : 0;
+    // s_memtime ticks per s_memrealtime tick (100 MHz), over all waves of the march: the clock the kernel ran at
+    stats->shader_clock_mhz = c[CNT_REAL] ? (float)((double)c[CNT_CLK] / (double)c[CNT_REAL] * 100.0) : 0.f;
     return 0;
 }
 
@@ -1569,34 +1642,92 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
                 (long long)src_end, scene ? scene->dev.num_sources : -1);
         return 1;
     }
+    if (stats && scene->win_open) {
+        fprintf(stderr, "photon: photon_trace: per-call stats inside an open statistics window (photon_scene_stats_begin); "
+                        "pass stats = NULL and read them with photon_scene_stats_end\n");
+        return 1;
+    }
     return guarded("photon_trace", [&]() -> int {
         hipStream_t stream = (hipStream_t)stream_p;
         const unsigned rps = (unsigned)scene->dev.rays_per_source;
+        size_t w0 = 0, w1 = 0;
         if (stats) {
             PH_CHECK(hipMemsetAsync(scene->d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long), stream));
             PH_CHECK(hipEventRecord(scene->ev[0], stream));
+        } else if (scene->win_open) {
+            { const int rc = window_event(scene, &w0); if (rc) return rc; }
+            { const int rc = window_event(scene, &w1); if (rc) return rc; }
+            PH_CHECK(hipEventRecord(scene->win_events[w0], stream));
         }
         float march_ms = 0.f;
-        { const int rc = trace_accumulate(scene, vol, ray_tracing_algorithm, src_begin, src_end, stream, stats != nullptr, &march_ms); if (rc) return rc; }
+        const int timed = stats ? 1 : (scene->win_open ? 2 : 0);
+        { const int rc = trace_accumulate(scene, vol, ray_tracing_algorithm, src_begin, src_end, stream, timed, &march_ms); if (rc) return rc; }
         { const int rc = end_accumulate(scene, d_image, stream); if (rc) return rc; }
         if (stats) {
             PH_CHECK(hipEventRecord(scene->ev[3], stream));
             PH_CHECK(hipEventSynchronize(scene->ev[3]));
-            std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
-            PH_CHECK(hipMemcpy(slots.data(), scene->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            unsigned long long c[CNT_N] = {0, 0, 0, 0, 0};
-            for (int k = 0; k < kCounterSlots; k++)
-                for (int j = 0; j < CNT_N; j++) c[j] += slots[(size_t)k * kCounterStride + j];
             memset(stats, 0, sizeof *stats);
+            { const int rc = read_counters(scene, vol != nullptr, stats); if (rc) return rc; }
             stats->rays_launched = (uint64_t)(src_end - src_begin) * rps;
-            stats->rays_on_sensor = c[CNT_ON_SENSOR];
-            stats->rk_iterations = c[CNT_ITER];
-            stats->volume_samples = c[CNT_SAMPLES];
-            stats->sensor_taps = c[CNT_TAPS];
-            stats->rays_marched = vol ? c[CNT_MARCHED] : 0;
             stats->march_ms = march_ms;
+            stats->traces = 1;
             PH_CHECK(hipEventElapsedTime(&stats->total_ms, scene->ev[0], scene->ev[3]));
+        } else if (scene->win_open) {
+            PH_CHECK(hipEventRecord(scene->win_events[w1], stream));
+            scene->win_total.emplace_back(w0, w1);
+            scene->win_rays += (uint64_t)(src_end - src_begin) * rps;
+            scene->win_traces += 1;
+            scene->win_have_volume = scene->win_have_volume || vol != nullptr;
         }
+        return 0;
+    });
+}
+
+// Statistics over a WINDOW of photon_trace calls without a host synchronisation inside it: _begin zeroes the counters (on
+// the stream), every photon_trace(stats = NULL) of this scene up to _end records its events on its stream and lets the
+// counters run; _end waits for the stream and returns the sums (march_ms, total_ms: summed over the traces; counters:
+// summed over the traces; shader_clock_mhz: over all march waves of the window).
+extern "C" int photon_scene_stats_begin(photon_scene_t *scene, void *stream_p) {
+    if (!scene) return 1;
+    return guarded("photon_scene_stats_begin", [&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_p;
+        PH_CHECK(hipMemsetAsync(scene->d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long), stream));
+        scene->win_used = 0;
+        scene->win_march.clear();
+        scene->win_total.clear();
+        scene->win_rays = 0;
+        scene->win_traces = 0;
+        scene->win_have_volume = false;
+        scene->win_open = true;
+        return 0;
+    });
+}
+
+extern "C" int photon_scene_stats_end(photon_scene_t *scene, void *stream_p, photon_trace_stats_t *stats) {
+    if (!scene || !stats || !scene->win_open) {
+        fprintf(stderr, "photon: photon_scene_stats_end: no open statistics window\n");
+        return 1;
+    }
+    return guarded("photon_scene_stats_end", [&]() -> int {
+        scene->win_open = false;
+        PH_CHECK(hipStreamSynchronize((hipStream_t)stream_p));
+        memset(stats, 0, sizeof *stats);
+        { const int rc = read_counters(scene, scene->win_have_volume, stats); if (rc) return rc; }
+        double march = 0.0, total = 0.0;
+        for (const auto &pr : scene->win_march) {
+            float ms = 0.f;
+            PH_CHECK(hipEventElapsedTime(&ms, scene->win_events[pr.first], scene->win_events[pr.second]));
+            march += ms;
+        }
+        for (const auto &pr : scene->win_total) {
+            float ms = 0.f;
+            PH_CHECK(hipEventElapsedTime(&ms, scene->win_events[pr.first], scene->win_events[pr.second]));
+            total += ms;
+        }
+        stats->march_ms = (float)march;
+        stats->total_ms = (float)total;
+        stats->rays_launched = scene->win_rays;
+        stats->traces = scene->win_traces;
         return 0;
     });
 }
@@ -2047,7 +2178,7 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
             }
             const DumpDev dump{d_fpos, d_fdir, num_lightrays_save, d_ipos, d_idir, inter ? num_intermediate_positions_save : 0};
             rc = launch_chunk(scene, vol, ray_tracing_algorithm, k * chunk, std::min(num_particles, (k + 1) * chunk),
-                              dump, nullptr, false);
+                              dump, nullptr, nullptr, nullptr);
             if (rc) break;
             bool wrote = true;                                          // a dump that cannot be written fails the call
             PH_VOID(hipMemcpy(host.data(), d_fpos, nsave * sizeof(float), hipMemcpyDeviceToHost));

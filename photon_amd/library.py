@@ -41,7 +41,7 @@ class photon_trace_stats_t(ctypes.Structure):
     _fields_ = [("rays_launched", ctypes.c_uint64), ("rays_on_sensor", ctypes.c_uint64),
                 ("rk_iterations", ctypes.c_uint64), ("volume_samples", ctypes.c_uint64),
                 ("sensor_taps", ctypes.c_uint64), ("march_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("rays_marched", ctypes.c_uint64)]
+                ("rays_marched", ctypes.c_uint64), ("shader_clock_mhz", ctypes.c_float), ("traces", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -120,6 +120,10 @@ class PhotonLibrary:
         L.photon_scene_set_skip_doomed.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.photon_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(photon_trace_stats_t)]
+        self.has_stats_window = hasattr(L, "photon_scene_stats_begin")     # absent from libraries built before round 3 (A/B runs)
+        if self.has_stats_window:
+            L.photon_scene_stats_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            L.photon_scene_stats_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(photon_trace_stats_t)]
         L.photon_trace_volume_rays.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p]
         L.photon_sources_bos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -365,6 +369,22 @@ class Scene:
                                         ctypes.c_void_p(int(stream)) if stream else None,
                                         ctypes.byref(stats) if stats is not None else None)
         self._lib._check(rc, "photon_trace")
+        return stats
+
+    @property
+    def has_stats_window(self) -> bool:
+        return self._lib.has_stats_window
+
+    def stats_begin(self, stream: int = 0):
+        """Open a statistics window: traces without want_stats record their events and let the counters run."""
+        self._lib._check(self._lib.lib.photon_scene_stats_begin(self.handle, ctypes.c_void_p(int(stream)) if stream else None),
+                         "photon_scene_stats_begin")
+
+    def stats_end(self, stream: int = 0):
+        """Wait for the stream and return the window's sums (photon_trace_stats_t; .traces = calls covered)."""
+        stats = photon_trace_stats_t()
+        self._lib._check(self._lib.lib.photon_scene_stats_end(self.handle, ctypes.c_void_p(int(stream)) if stream else None,
+                                                              ctypes.byref(stats)), "photon_scene_stats_end")
         return stats
 
     def set_noise(self, add_pos_noise=False, pos_noise_std=0.0, add_ngrad_noise=False, ngrad_noise_std=0.0, seed=0):

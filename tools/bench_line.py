@@ -8,7 +8,7 @@ for path in sys.argv[1:]:
         lines = [x for x in open(path) if x.startswith("{")]
         d = json.loads(lines[-1])
         r = d["roofline"]
-        print(path, "Mrays/s", d["value"], "ms/step", d["ms_per_step"], "march_ms", r["kernel_ms"],
-              "valu", r.get("valu_f32", {}).get("frac"), "copy GB/s", r.get("hbm_copy_measured_gbs"))
+        print(path, "Mrays/s", d["value"], "ms/step", d["ms_per_step"], "march_ms", r["kernel_ms"], "frac", r.get("frac"),
+              "clock_mhz", r.get("clock_mhz"), "frac_at_clock", r.get("frac_at_clock"), "check", d.get("check"))
     except Exception as e:                                     # noqa: BLE001
         print(path, "unreadable:", e)
