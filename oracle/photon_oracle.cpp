@@ -131,14 +131,18 @@ inline f4 tex3d_linear(const Volume &v, const std::vector<f4> &t, float x, float
     return lerp4(c0, c1, c);
 }
 
-// bspline_weights, CubicInterpolationCUDA/code/internal/bspline_kernel.cu:83-94
+// bspline_weights, CubicInterpolationCUDA/code/internal/bspline_kernel.cu:83-94.  w0, w3 as spelled there; the middle
+// weights 2/3 - f^2 (2 - f) / 2 in the Horner form 2/3 + f^2 (f / 2 - 1) with two fused multiply-adds (round 3; rounds
+// 1-2 spelled them literally: four roundings instead of two).  This is the DEFINED form the HIP kernels reproduce bit
+// for bit; it is pinned against an f64 evaluation of the same 64-tap sum in tests/test_oracle_golden.py.  The
+// reference never executes its tricubic path (interpolation_scheme hard-wired to 1), so no reference bits exist.
 inline void bspline_weights(float f, float &w0, float &w1, float &w2, float &w3) {
     const float one_frac = 1.0f - f;
     const float squared = f * f;
     const float one_sqd = one_frac * one_frac;
     w0 = 1.0f / 6.0f * one_sqd * one_frac;
-    w1 = 2.0f / 3.0f - 0.5f * squared * (2.0f - f);
-    w2 = 2.0f / 3.0f - 0.5f * one_sqd * (2.0f - one_frac);
+    w1 = fmaf(squared, fmaf(0.5f, f, -1.0f), 2.0f / 3.0f);
+    w2 = fmaf(one_sqd, fmaf(0.5f, one_frac, -1.0f), 2.0f / 3.0f);
     w3 = 1.0f / 6.0f * squared * f;
 }
 

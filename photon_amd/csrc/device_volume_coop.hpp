@@ -90,6 +90,132 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     return acc;
 }
 
+#ifndef PHOTON_DPP_SLAB
+#define PHOTON_DPP_SLAB 1
+#endif
+// The coherent tile's 64-tap sum with z-slab 0 served from REGISTERS instead of LDS (PHOTON_DPP_SLAB=1): `reg` holds, in
+// every 16-lane row of the wave, the 16 texels of slab 0 (lane l: texel l & 15), and its 16 taps are v_fmac_f32_dpp with
+// row_newbcast:k -- every lane multiplies ITS weight with lane k's texel.  16 of the sample's 64 broadcast ds_read_b128
+// disappear; a DPP multiply-add costs more issue time than a plain one (round 2's micro-benchmark: ~1.35x), and the
+// kernel's CYCLES per sample stay what they were -- but the chip, which holds its clock down under this kernel's load,
+// runs the version with fewer LDS reads ~2.7 % faster (same box, round 3: 2130 -> 2188 MHz, 62.4 -> 60.8 ms).
+// Same taps, same order, same fmaf chain: same bits.
+// ONE asm block: the four reads of slab 1's first row are issued, the 64 register-slab taps run while they are in
+// flight, and the block ends on the wait for them (long since landed) -- so the compiler, which does not see LDS
+// traffic inside inline asm, finds nothing outstanding after it.  The DPP operand registers (reg) are not written
+// inside the block; the s_nop covers the EXEC-write / VALU-write -> DPP hazards of whatever precedes it (the compiler's
+// hazard recogniser does not look into inline asm).
+__device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const float (&wx)[4], const float (&wy)[4],
+                                                const float (&wz)[4]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    float wxy[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) wxy[b][a] = wx[a] * wy[b];
+    v4f t0, t1, t2, t3;
+    f4 s;
+    const unsigned lds = (unsigned)(size_t)blk;                     // LDS byte address of the tile (low half of the flat address)
+    asm volatile(
+            "ds_read_b128 %4, %28 offset:256\n\t"
+            "ds_read_b128 %5, %28 offset:272\n\t"
+            "ds_read_b128 %6, %28 offset:288\n\t"
+            "ds_read_b128 %7, %28 offset:304\n\t"
+            "s_nop 4\n\t"
+            "v_mul_f32_dpp %0, %8, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %9, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %2, %10, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %3, %11, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %8, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %9, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %10, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %11, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(s.x), "=&v"(s.y), "=&v"(s.z), "=&v"(s.w), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(reg.x), "v"(reg.y), "v"(reg.z), "v"(reg.w), "v"(wxy[0][0]), "v"(wxy[0][1]), "v"(wxy[0][2]), "v"(wxy[0][3]),
+              "v"(wxy[1][0]), "v"(wxy[1][1]), "v"(wxy[1][2]), "v"(wxy[1][3]), "v"(wxy[2][0]), "v"(wxy[2][1]), "v"(wxy[2][2]),
+              "v"(wxy[2][3]), "v"(wxy[3][0]), "v"(wxy[3][1]), "v"(wxy[3][2]), "v"(wxy[3][3]), "v"(lds)
+            : "memory");
+    f4 t[4] = {f4{t0.x, t0.y, t0.z, t0.w}, f4{t1.x, t1.y, t1.z, t1.w}, f4{t2.x, t2.y, t2.z, t2.w}, f4{t3.x, t3.y, t3.z, t3.w}};
+    f4 acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
+    float w0 = wxy[0][0];
+#pragma unroll
+    for (int r = 4; r < 16; r++) {                                  // slabs 1..3 from the LDS tile, as in cubic_taps_lds
+        const int b = r & 3, c = r >> 2;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const f4 ta = t[a];
+            const float w = (a == 0 && b == 0) ? w0 : wxy[b][a];
+            if (a == 0 && b == 0) s = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
+            else s = f4{fmaf(w, ta.x, s.x), fmaf(w, ta.y, s.y), fmaf(w, ta.z, s.z), fmaf(w, ta.w, s.w)};
+            asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w) : : "memory");
+            if (r < 15) t[a] = ldtexel(blk + ((r + 1) >> 2) * 16 + ((r + 1) & 3) * 4 + a);
+            asm volatile("" : "+v"(w0) : : "memory");
+        }
+        if (b == 3) {
+            acc = f4{fmaf(wz[c], s.x, acc.x), fmaf(wz[c], s.y, acc.y), fmaf(wz[c], s.z, acc.z), fmaf(wz[c], s.w, acc.w)};
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
+        }
+    }
+    return acc;
+}
+
 // Lane predicates of the march are kept as WAVE MASKS (64-bit, wave-uniform, SGPR pairs): a mask comes out of
 // ballot(one comparison) -- a single v_cmp writing an SGPR pair -- and masks combine with integer & | ~ on the scalar
 // unit.  A predicate that is an AND / OR of i1 values reaches ballot() as a 0/1 VGPR instead (v_cndmask + v_cmp per use),
@@ -101,9 +227,9 @@ __device__ __forceinline__ bool lane_of(unsigned long long mask) { return __buil
 // samples of a ray advance by half a texel, so about every other sample finds its block / brick still there
 // and skips the fetch.  A block is named by the BIT PATTERNS of its three floor() values (readlane'd from its
 // leader): comparing those needs no float -> int conversion on the per-sample path.
-struct Parked { int ti, tj, tk; int bi, bj, bk; };
+struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; };      // reg: z-slab 0 of the parked tile in registers (PHOTON_DPP_SLAB, per lane)
 __device__ __forceinline__ Parked parked_none() {                // 0x7fffffff: a NaN pattern no floor() of a sampled coordinate has
-    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}};
 }
 
 // Block coherence of a wave's sample: the first sampling lane leads; the wave is coherent when every sampling lane
@@ -150,9 +276,10 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                 __builtin_amdgcn_wave_barrier();
                 *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
                 __builtin_amdgcn_wave_barrier();
+                if (PHOTON_DPP_SLAB) parked.reg = ldtexel(blk + (lane & 15));      // slab 0, once per block, into every 16-lane row
                 parked.ti = c.i; parked.tj = c.j; parked.tk = c.k;
             }
-            const f4 acc = cubic_taps_lds<4, 16>(blk, wx, wy, wz);
+            const f4 acc = PHOTON_DPP_SLAB ? cubic_taps_hybrid(blk, parked.reg, wx, wy, wz) : cubic_taps_lds<4, 16>(blk, wx, wy, wz);
             __builtin_amdgcn_wave_barrier();
             return acc;
         }

@@ -142,6 +142,53 @@ def test_tricubic_interpolates_at_the_knots(oracle):
     v.free()
 
 
+def tricubic_f64(coeffs, coords):
+    """The 64-tap tricubic B-spline sum in float64, written independently of the oracle's evaluation order: weights
+    from the textbook polynomials, texels floor(x - 0.5) - 1 .. + 2 with clamp addressing, one einsum per sample."""
+    nz, ny, nx, _ = coeffs.shape
+    c64 = coeffs.astype(np.float64)
+    out = np.empty((len(coords), 4))
+
+    def weights(f):
+        return np.array([(1 - f) ** 3 / 6, 2 / 3 - 0.5 * f * f * (2 - f), 2 / 3 - 0.5 * (1 - f) ** 2 * (1 + f), f ** 3 / 6])
+
+    for n, (x, y, z) in enumerate(np.asarray(coords, np.float32)):
+        g = np.array([x, y, z], np.float32) - np.float32(0.5)          # the f32 texel coordinate both samplers start from
+        base = np.floor(g)
+        f = (g - base).astype(np.float64)                               # f32 subtraction of nearby values: exact
+        ix = np.clip(int(base[0]) - 1 + np.arange(4), 0, nx - 1)
+        iy = np.clip(int(base[1]) - 1 + np.arange(4), 0, ny - 1)
+        iz = np.clip(int(base[2]) - 1 + np.arange(4), 0, nz - 1)
+        block = c64[np.ix_(iz, iy, ix)]                                 # [c][b][a][channel]
+        out[n] = np.einsum("c,b,a,cbaq->q", weights(f[2]), weights(f[1]), weights(f[0]), block)
+    return out
+
+
+def tricubic_anchor_case():
+    rng = np.random.default_rng(11)
+    n = 20
+    rho = (1.0 + 0.5 * rng.random((n, n, n))).astype(np.float32)
+    coords = np.concatenate([rng.uniform(0.0, n, (600, 3)),                      # anywhere, including the clamped rim
+                             np.array([[0.5, 0.5, 0.5], [n - 0.5, 3.25, 7.75], [4.0, 4.0, 4.0], [1.0e-3, 19.999, 10.5]])]).astype(np.float32)
+    return rho, coords
+
+
+def test_tricubic_sum_agrees_with_f64_evaluation(oracle):
+    """Anchor of the DEFINED evaluation order (slab order, Horner weights): whatever order oracle and kernels share,
+    the result must be the 64-tap B-spline sum -- here evaluated in float64 with textbook weights and no shared code --
+    to a few f32 roundings of the largest tap.  A reassociation moves results by ulps; a wrong weight, tap or clamp by
+    1e-2 .. 1."""
+    rho, coords = tricubic_anchor_case()
+    v = oracle.volume_from_density(rho, (100.0, 100.0, 100.0), (0.0, 0.0, 750e3), 2)
+    coeffs = v.download(True)
+    got = v.sample(coords).astype(np.float64)
+    want = tricubic_f64(coeffs, coords)
+    scale = np.abs(coeffs.reshape(-1, 4)).max(axis=0)
+    err = np.abs(got - want) / scale
+    assert err.max() < 8 * 2.0 ** -24, err.max()                  # measured 1.1e-7 (~2 ulp of the largest tap)
+    v.free()
+
+
 def test_trilinear_is_exact_at_texel_centres_and_linear_between(oracle):
     rng = np.random.default_rng(3)
     n = 12

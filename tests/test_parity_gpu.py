@@ -105,6 +105,22 @@ def test_sampler_bit_exact(vol_pair, interp):
     assert_bit_equal(g.sample(coords), o.sample(coords), f"sampler interp {interp}")
 
 
+def test_tricubic_sampler_agrees_with_f64_evaluation(photon):
+    """The product's tricubic sampler (photon_volume_sample through the C-ABI) against a float64 evaluation of the
+    64-tap B-spline sum that shares no code with kernels or oracle (tests/test_oracle_golden.py: textbook weights,
+    einsum): the anchor of the evaluation order both sides define (slab order, Horner weights).  Tolerance: 8 f32
+    roundings of the largest tap; a wrong weight, tap or clamp shows at 1e-2 .. 1."""
+    from test_oracle_golden import tricubic_anchor_case, tricubic_f64
+    rho, coords = tricubic_anchor_case()
+    v = photon.volume_from_density(rho, (100.0, 100.0, 100.0), (0.0, 0.0, 750e3), 2)
+    coeffs = v.download(True)
+    got = v.sample(coords).astype(np.float64)
+    want = tricubic_f64(coeffs, coords)
+    err = np.abs(got - want) / np.abs(coeffs.reshape(-1, 4)).max(axis=0)
+    assert err.max() < 8 * 2.0 ** -24, err.max()
+    v.free()
+
+
 @pytest.mark.parametrize("algorithm", [1, 2])
 @pytest.mark.parametrize("interp", [1, 2])
 def test_march_bit_exact(vol_pair, interp, algorithm):
