@@ -76,7 +76,7 @@ __device__ __forceinline__ f4 tex3d_linear(const VolumeDev &v, float x, float y,
 // bspline_weights (CubicInterpolationCUDA/code/internal/bspline_kernel.cu:83-94): the uniform cubic B-spline's four
 // weights at fraction f.  w0 and w3 as the reference spells them; the two middle weights 2/3 - f^2 (2 - f) / 2 in the
 // Horner form fmaf(f^2, fmaf(0.5, f, -1), 2/3) -- 11 instructions per axis instead of 15, rounded twice instead of four
-// times.  The DEFINED form: oracle/photon_oracle.cpp evaluates the same expressions; both are pinned to an f64
+// times.  The DEFINED form: the CPU checker evaluates the same expressions; both are pinned to an f64
 // evaluation of the 64-tap sum (tests/test_oracle_golden.py).  The reference itself never executes this code path
 // (interpolation_scheme is hard-wired to trilinear), so there are no reference bits to match.
 __device__ __forceinline__ void bspline_weights(float f, float &w0, float &w1, float &w2, float &w3) {
