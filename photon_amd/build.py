@@ -38,8 +38,6 @@ HIPCC_FLAGS = [
 ]
 # RUNPATH: the unversioned ROCm prefix, so the library finds libamdhip64 on a box whose ROCm point release differs
 # from the build box's (hipcc's own default is the versioned /opt/rocm-X.Y.Z/lib of the machine it ran on).
-LINK_FLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-Wl,--enable-new-dtags", "-Wl,-rpath,/opt/rocm/lib",
-              "-L/opt/rocm/lib", "-lamdhip64"]
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 
 
@@ -48,6 +46,20 @@ def hipcc_path() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
+
+
+def rocm_lib_dir() -> str:
+    """lib/ of the ROCm installation whose hipcc compiles the library ($ROCM_PATH, else the prefix hipcc sits in,
+    symlinks unresolved: /opt/rocm rather than /opt/rocm-7.2.0) -- the RUNPATH and the -L of the link."""
+    prefix = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(hipcc_path()))
+    lib = os.path.join(prefix, "lib")
+    return lib if os.path.isdir(lib) else "/opt/rocm/lib"
+
+
+def link_flags():
+    lib = rocm_lib_dir()
+    return ["-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-Wl,--enable-new-dtags", f"-Wl,-rpath,{lib}", f"-L{lib}",
+            "-lamdhip64"]
 
 
 def needs_build() -> bool:
@@ -83,7 +95,7 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out
         with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
             objs = list(pool.map(lambda src: _compile(src, extra_flags, verbose, obj_dir), SOURCES))
         tmp = target + f".tmp{os.getpid()}"
-        cmd = [hipcc_path()] + LINK_FLAGS + ["-o", tmp] + objs
+        cmd = [hipcc_path()] + link_flags() + ["-o", tmp] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr, flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC, stdout=sys.stderr)

@@ -36,6 +36,17 @@ namespace photon {
 #ifndef PHOTON_TILE_REUSE
 #define PHOTON_TILE_REUSE 1
 #endif
+// Row pitch of the brick in LDS, in texels.  The brick is 8 texels wide; with a pitch of 8 the 16-byte reads of lanes
+// whose blocks sit two rows apart land on the same four banks (a ds_read_b128 serves 16 lanes per LDS cycle from 64
+// banks: texel index mod 16 names the bank group, and 8 * dj mod 16 only takes two values).  A pitch of 12 makes
+// (di + 12 dj) mod 16 distinct over any 4 x 4 window of block offsets: the patch a lens-major wave covers.  Immediate
+// offsets stay immediate (a padded pitch, not an XOR swizzle, whose per-tap addresses would each cost an instruction).
+#ifndef PHOTON_BRICK_PITCH
+#define PHOTON_BRICK_PITCH 12
+#endif
+constexpr int kBrickPitch = PHOTON_BRICK_PITCH;                  // texels between consecutive rows of the brick
+constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels between consecutive z-slabs
+constexpr int kWaveLdsTexels = 64 + 4 * kBrickSlab;             // per wave: the 4x4x4 tile + the 8x8x4 brick (8x8x2 for trilinear)
 
 // 64-tap sum (slab order) over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
 // is one broadcast ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues
@@ -302,19 +313,22 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         const bool in_brick = !done && bk == ck && (unsigned)di <= 4u && (unsigned)dj <= 4u;
         if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
             __builtin_amdgcn_wave_barrier();
+            int l = lane;
+            asm volatile("" : "+v"(l));                         // keep the brick's lane offsets out of the march loop's live registers
+            const int slot = (l & 7) + ((l >> 3) & 7) * kBrickPitch;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int t = lane + 64 * j;
+                const int t = l + 64 * j;
                 const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
                           tz = clampi(ck - 1 + (t >> 6), 0, v.nz - 1);
                 const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-                *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+                *reinterpret_cast<float4 *>(brick + slot + j * kBrickSlab) = make_float4(tv.x, tv.y, tv.z, tv.w);
             }
             __builtin_amdgcn_wave_barrier();
             parked.bi = ci; parked.bj = cj; parked.bk = ck;
         }
         if (in_brick) {
-            acc = cubic_taps_lds<8, 64>(brick + (dj * 8 + di), wx, wy, wz);
+            acc = cubic_taps_lds<kBrickPitch, kBrickSlab>(brick + (dj * kBrickPitch + di), wx, wy, wz);
             done = true;
         }
         __builtin_amdgcn_wave_barrier();
@@ -403,21 +417,25 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         const bool in_brick = !done && bk == ck && (unsigned)di <= 6u && (unsigned)dj <= 6u;
         if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
             __builtin_amdgcn_wave_barrier();
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            const int slot = (l & 7) + ((l >> 3) & 7) * kBrickPitch;
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int t = lane + 64 * j;
+                const int t = l + 64 * j;
                 const int tx = clampi(ci - 3 + (t & 7), 0, v.nx - 1), ty = clampi(cj - 3 + ((t >> 3) & 7), 0, v.ny - 1),
                           tz = clampi(ck + (t >> 6), 0, v.nz - 1);
                 const f4 tv = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-                *reinterpret_cast<float4 *>(brick + t) = make_float4(tv.x, tv.y, tv.z, tv.w);
+                *reinterpret_cast<float4 *>(brick + slot + j * kBrickSlab) = make_float4(tv.x, tv.y, tv.z, tv.w);
             }
             __builtin_amdgcn_wave_barrier();
             parked.bi = ci; parked.bj = cj; parked.bk = ck;
         }
         if (in_brick) {
-            const f4 *q = brick + (dj * 8 + di);
-            const f4 c00 = lerp4(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4(ldtexel(q + 8), ldtexel(q + 9), a);
-            const f4 c01 = lerp4(ldtexel(q + 64), ldtexel(q + 65), a), c11 = lerp4(ldtexel(q + 72), ldtexel(q + 73), a);
+            const f4 *q = brick + (dj * kBrickPitch + di);
+            const f4 c00 = lerp4(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4(ldtexel(q + kBrickPitch), ldtexel(q + kBrickPitch + 1), a);
+            const f4 c01 = lerp4(ldtexel(q + kBrickSlab), ldtexel(q + kBrickSlab + 1), a),
+                     c11 = lerp4(ldtexel(q + kBrickSlab + kBrickPitch), ldtexel(q + kBrickSlab + kBrickPitch + 1), a);
             const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
             acc = lerp4(c0, c1, c);
             done = true;

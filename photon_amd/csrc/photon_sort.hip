@@ -65,42 +65,66 @@ __global__ __launch_bounds__(256) void morton_keys_kernel(const float *__restric
     idx[i] = first + (int)i;
 }
 
+
+__global__ void init_box_kernel(unsigned *box) {
+    if (threadIdx.x < 4) box[threadIdx.x] = (threadIdx.x & 1) ? 0u : 0xffffffffu;     // {min x, max x, min y, max y} encoded
+}
+
 }  // namespace
+
+// Scratch of the sort, owned by the caller (the scene) and grown on demand: with it a sort allocates nothing and never
+// waits for the host -- photon_trace stays asynchronous on its stream when a lens-major launch has to order a new range.
+struct photon_sort_scratch {
+    unsigned *box = nullptr, *keys = nullptr;       // keys: 2 x capacity (in, out)
+    int *idx = nullptr;
+    void *tmp = nullptr;
+    size_t capacity = 0, tmp_bytes = 0;
+};
+
+void photon_sort_scratch_free(photon_sort_scratch *s) {
+    if (!s) return;
+    if (s->box) (void)hipFree(s->box);
+    if (s->keys) (void)hipFree(s->keys);
+    if (s->idx) (void)hipFree(s->idx);
+    if (s->tmp) (void)hipFree(s->tmp);
+    *s = photon_sort_scratch{};
+}
 
 // perm_out[k] (device, n entries) = index, in the CALLER's source numbering, of the k-th source of
 // [first, first + n) in Morton order.  x, y: device pointers to the whole source arrays.  Asynchronous on
-// `stream` except for the temporary allocations.  Returns 0 or a HIP error code.
-int photon_morton_order(const float *d_x, const float *d_y, int first, long long n, int *d_perm_out, hipStream_t stream) {
+// `stream`; allocates only when the scratch has to grow.  Returns 0 or a HIP error code.
+int photon_morton_order(const float *d_x, const float *d_y, int first, long long n, int *d_perm_out, hipStream_t stream,
+                        photon_sort_scratch *sc) {
     if (n <= 0) return 0;
-    unsigned *d_box = nullptr, *d_keys = nullptr, *d_keys_out = nullptr;
-    int *d_idx = nullptr;
-    void *d_tmp = nullptr;
-    size_t tmp_bytes = 0;
     hipError_t e = hipSuccess;
-    auto done = [&](hipError_t err, int line) {
-        if (err != hipSuccess) fprintf(stderr, "photon: HIP error %d (%s) at %s:%d\n", (int)err, hipGetErrorString(err), __FILE__, line);
-        if (d_box) (void)hipFree(d_box);
-        if (d_keys) (void)hipFree(d_keys);
-        if (d_idx) (void)hipFree(d_idx);
-        if (d_tmp) (void)hipFree(d_tmp);
-        return (int)err;
-    };
-#define PS_CHECK(expr) do { e = (expr); if (e != hipSuccess) return done(e, __LINE__); } while (0)
-    PS_CHECK(hipMalloc((void **)&d_box, 4 * sizeof(unsigned)));
-    PS_CHECK(hipMalloc((void **)&d_keys, 2 * (size_t)n * sizeof(unsigned)));
-    d_keys_out = d_keys + n;
-    PS_CHECK(hipMalloc((void **)&d_idx, (size_t)n * sizeof(int)));
-    const unsigned init[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
-    PS_CHECK(hipMemcpyAsync(d_box, init, sizeof init, hipMemcpyHostToDevice, stream));
+#define PS_CHECK(expr) do { e = (expr); if (e != hipSuccess) { fprintf(stderr, "photon: HIP error %d (%s) at %s:%d\n", (int)e, hipGetErrorString(e), __FILE__, __LINE__); return (int)e; } } while (0)
+    size_t need_tmp = 0;
+    PS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, need_tmp, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr, (int *)nullptr, (int)n, 0, 32, stream));
+    if (!sc->box) PS_CHECK(hipMalloc((void **)&sc->box, 4 * sizeof(unsigned)));
+    if (sc->capacity < (size_t)n) {
+        if (sc->keys) { (void)hipFree(sc->keys); sc->keys = nullptr; }
+        if (sc->idx) { (void)hipFree(sc->idx); sc->idx = nullptr; }
+        sc->capacity = 0;
+        PS_CHECK(hipMalloc((void **)&sc->keys, 2 * (size_t)n * sizeof(unsigned)));
+        PS_CHECK(hipMalloc((void **)&sc->idx, (size_t)n * sizeof(int)));
+        sc->capacity = (size_t)n;
+    }
+    if (sc->tmp_bytes < need_tmp || !sc->tmp) {
+        if (sc->tmp) { (void)hipFree(sc->tmp); sc->tmp = nullptr; }
+        sc->tmp_bytes = 0;
+        PS_CHECK(hipMalloc(&sc->tmp, need_tmp ? need_tmp : 16));
+        sc->tmp_bytes = need_tmp ? need_tmp : 16;
+    }
+    unsigned *keys_out = sc->keys + sc->capacity;
+    hipLaunchKernelGGL(init_box_kernel, dim3(1), dim3(64), 0, stream, sc->box);
+    PS_CHECK(hipGetLastError());
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, stream, d_x + first, d_y + first, n, d_box);
+    hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, stream, d_x + first, d_y + first, n, sc->box);
     PS_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(morton_keys_kernel, dim3(blocks), dim3(256), 0, stream, d_x + first, d_y + first, n, d_box, first, d_keys, d_idx);
+    hipLaunchKernelGGL(morton_keys_kernel, dim3(blocks), dim3(256), 0, stream, d_x + first, d_y + first, n, sc->box, first, sc->keys, sc->idx);
     PS_CHECK(hipGetLastError());
-    PS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_out, d_idx, d_perm_out, (int)n, 0, 32, stream));
-    PS_CHECK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    PS_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_out, d_idx, d_perm_out, (int)n, 0, 32, stream));
-    PS_CHECK(hipStreamSynchronize(stream));         // the temporaries die here
+    size_t tmp_bytes = sc->tmp_bytes;
+    PS_CHECK(hipcub::DeviceRadixSort::SortPairs(sc->tmp, tmp_bytes, sc->keys, keys_out, sc->idx, d_perm_out, (int)n, 0, 32, stream));
 #undef PS_CHECK
-    return done(hipSuccess, 0);
+    return 0;
 }

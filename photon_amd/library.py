@@ -58,19 +58,31 @@ def _ptr(a: np.ndarray):
 def _one_hip_runtime_per_process():
     """PyTorch-ROCm bundles its own libamdhip64; the library's RUNPATH names the system's.  A process that ends up with
     both mapped has two HIP runtimes, and whichever touches the GPU second finds no device (seen both ways round on
-    the MI355X boxes).  Loaded FIRST, torch's copy is the one the library binds to by SONAME -- so when torch is
-    installed (this repo's tests, bench and smoke use it for device tensors and torch.distributed) it is imported before
-    the library is mapped.  photon itself has no torch: the library then maps the system runtime on its own.
-    PHOTON_NO_TORCH_PRELOAD=1 skips this."""
-    import importlib.util
+    the MI355X boxes).  Whoever shares torch device tensors with the library (this repo's tests, bench.py, smoke())
+    therefore imports torch FIRST, explicitly: the library then binds to torch's copy by SONAME.  The library itself
+    never imports torch behind the caller's back -- photon's own Python has none and gets the system runtime the library
+    was built against.  PHOTON_PRELOAD_TORCH=1 asks for the import here (a caller that cannot order its imports)."""
     import sys
-    if "torch" in sys.modules or os.environ.get("PHOTON_NO_TORCH_PRELOAD"):
+    if "torch" in sys.modules or not os.environ.get("PHOTON_PRELOAD_TORCH"):
         return
     try:
-        if importlib.util.find_spec("torch") is not None:
-            import torch  # noqa: F401
+        import torch  # noqa: F401
     except Exception:       # noqa: BLE001  -- a broken torch must not keep the library from loading
         pass
+
+
+def mapped_hip_runtimes():
+    """Paths of every libamdhip64 mapped into this process (more than one = the two-runtime trap above)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                path = ln.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64" in path and path not in found:
+                    found.append(path)
+    except OSError:
+        pass
+    return found
 
 
 class PhotonLibrary:
@@ -91,6 +103,12 @@ class PhotonLibrary:
         self.path = path
         _one_hip_runtime_per_process()
         self.lib = ctypes.CDLL(path)
+        self.hip_runtimes = mapped_hip_runtimes()
+        if os.environ.get("PHOTON_VERBOSE") or len(self.hip_runtimes) > 1:
+            import sys
+            print(f"photon: {path} runs on {', '.join(self.hip_runtimes) or 'an unidentified HIP runtime'}"
+                  + (" -- TWO HIP runtimes in one process: import torch before the library" if len(self.hip_runtimes) > 1 else ""),
+                  file=sys.stderr)
         L = self.lib
         self.start_ray_tracing = bind_start_ray_tracing(L)
         L.photon_version.restype = ctypes.c_char_p

@@ -60,3 +60,79 @@ def load_fixture_call(name: str):
     from photon_amd.ray_tracing import RayTracingCall
     return RayTracingCall.from_fixture(os.path.join(GOLDEN, f"abi_{name}.json"), os.path.join(GOLDEN, f"abi_{name}.npz"),
                                        density_dir=GOLDEN)
+
+
+# ---- the BOS image pair with ray dumps that pins the dump wire format to the reference's own reader -------------------
+DUMP_SLOTS = 6
+
+
+def dump_pair_calls(workdir: str):
+    """Deterministic small BOS pair (image 1 without, image 2 with the density-gradient volume) that writes every ray
+    dump the reference knows: pos_/dir_ per image, intermediate_pos_/intermediate_dir_ for image 2, in the folder
+    layout its reader expects (light_ray_processing.py:160-207).  Used by tests/golden/make_golden.py (oracle writes,
+    the REFERENCE's reader parses -> dumps_reference_reader.npz) and by the tests (oracle / GPU write, our parse)."""
+    from photon_amd import scenes
+    rho, sp, org = scenes.bos_volume(40)
+    nrrd = scenes.write_nrrd(os.path.join(workdir, "dump_pair_40.nrrd"), rho, sp, org)
+    calls = []
+    for im, grad in (("im1", False), ("im2", True)):
+        c = scenes.bos_scene(n_dots=3, points_per_dot=8, rays_per_source=25, density_grad_filename=nrrd if grad else "", seed=5)
+        c.simulate_density_gradients = grad
+        c.ray_tracing_algorithm = 2 if grad else 0
+        c.save_lightrays, c.num_lightrays_save = True, c.num_rays
+        c.save_intermediate_ray_data, c.num_intermediate_positions_save = grad, DUMP_SLOTS if grad else 0
+        pdir = os.path.join(workdir, "light-ray-positions", im)
+        ddir = os.path.join(workdir, "light-ray-directions", im)
+        os.makedirs(pdir, exist_ok=True)
+        os.makedirs(ddir, exist_ok=True)
+        c.lightray_position_save_path, c.lightray_direction_save_path = pdir, ddir
+        calls.append(c)
+    return calls
+
+
+def parse_dump_pair(folder: str):
+    """Our reading of the dump wire format (include/parallel_ray_tracing.h): flat little-endian f32 triples, ray-major;
+    intermediates [ray][slot][3]; the reference's reader reports directions as arccos of the components."""
+    import numpy as np
+    out = {}
+    for im in ("im1", "im2"):
+        p = np.fromfile(os.path.join(folder, "light-ray-positions", im, "pos_0000.bin"), np.float32).reshape(-1, 3)
+        d = np.fromfile(os.path.join(folder, "light-ray-directions", im, "dir_0000.bin"), np.float32).reshape(-1, 3)
+        out[f"pos_{im}"], out[f"ang_{im}"] = p, np.arccos(d)
+    ip = np.fromfile(os.path.join(folder, "light-ray-positions", "im2", "intermediate_pos_0000.bin"), np.float32)
+    idr = np.fromfile(os.path.join(folder, "light-ray-directions", "im2", "intermediate_dir_0000.bin"), np.float32)
+    out["ipos"] = ip.reshape(-1, DUMP_SLOTS, 3)
+    out["iang"] = np.arccos(idr.reshape(-1, DUMP_SLOTS, 3))
+    return out
+
+
+# ---- end-to-end BOS displacement: constant density gradient between target and lens ----------------------------------
+def bos_displacement_case(workdir: str, target_px: float = 3.0):
+    """A BOS dot pattern rendered without (call 1) and through (call 2) a volume of constant d(rho)/dx sized so that the
+    reference's own paraxial relation (python_codes/nrrd_functions.py:60-82: epsilon = n_grad * del_z / n_0,
+    displacement = M * Z_D * epsilon / pixel_pitch) predicts a dot shift of `target_px` pixels.  Returns
+    (call_without, call_with, predicted_shift_px)."""
+    import numpy as np
+    from photon_amd import scenes
+    from photon_amd.ray_tracing import single_lens_camera
+    n, extent, pitch, K, rho_0 = 64, 66300.0, 17.0, 0.225e-3, 1.225
+    h = extent / (n - 1)
+    geom = single_lens_camera(lens_model="general", **scenes.SAMPLE_LENS)
+    M = scenes.SAMPLE_LENS["focal_length"] / (scenes.SAMPLE_LENS["object_distance"] - scenes.SAMPLE_LENS["focal_length"])
+    origin = (-extent / 2, -extent / 2, 300000.0)
+    Z_D = geom["z_object"] - (origin[2] + geom["z_offset"] + extent / 2)      # dot pattern to the middle of the volume
+    n_0 = K * rho_0 + 1
+    epsilon = target_px * pitch / (M * Z_D)
+    rho_grad = epsilon * n_0 / extent / K                                     # density per micron along x
+    rho = np.broadcast_to((rho_0 + rho_grad * np.arange(n) * h)[None, None, :], (n, n, n)).astype(np.float32)
+    nrrd = scenes.write_nrrd(os.path.join(workdir, "linear_density_64.nrrd"), rho, (h, h, h), origin)
+    kw = dict(n_dots=6, points_per_dot=30, rays_per_source=100, seed=7, field_half_width=1.5e4)
+    predicted = M * Z_D * (1 / n_0 * (K * rho_grad) * extent) / pitch          # the reference's formula, evaluated forward
+    return scenes.bos_scene(**kw), scenes.bos_scene(density_grad_filename=nrrd, **kw), predicted
+
+
+def image_centroid(img):
+    import numpy as np
+    img = np.asarray(img, np.float64)
+    rows, cols = np.indices(img.shape)
+    return (img * cols).sum() / img.sum(), (img * rows).sum() / img.sum()

@@ -365,8 +365,57 @@ def pins_golden():
     np.savez_compressed(os.path.join(OUT, "pins.npz"), **out)
 
 
+def dumps_golden():
+    """The ray-dump wire format as the REFERENCE's own reader sees it (light_ray_processing.py:74-207): the oracle writes
+    pos_/dir_/intermediate_*.bin for a small BOS pair (tests/conftest.py: dump_pair_calls), the reference's
+    load_light_ray_data / load_intermediate_light_ray_data / calculate_lightray_deflections parse them, the parsed arrays
+    are the fixture.  Import shims (this script only): the module pulls two plotting helpers of its author's environment
+    (not in the repository; neither is used by the readers) and sets a matplotlib option in its pre-3.3 list form."""
+    import types
+    import matplotlib
+    matplotlib.use("Agg")
+    matplotlib.rcParams.validate["text.latex.preamble"] = lambda v: "".join(v) if isinstance(v, list) else v
+    helper = types.ModuleType("modify_plt_settings")
+    helper.modify_plt_settings = lambda plt: plt
+    sys.modules.setdefault("modify_plt_settings", helper)
+    sys.modules.setdefault("loadmat_functions", types.ModuleType("loadmat_functions"))
+    import light_ray_processing as lrp
+    numpy_reshape = np.reshape
+
+    def reshape_numpy1(*args, **kw):                    # numpy 1 took reshape(a=..., newshape=...); numpy 2 made `a` positional-only
+        if "a" in kw:
+            args = (kw.pop("a"),) + args
+        if "newshape" in kw:
+            kw["shape"] = kw.pop("newshape")
+        return numpy_reshape(*args, **kw)
+    lrp.np.reshape = reshape_numpy1
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), "..", "oracle"))
+    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from conftest import DUMP_SLOTS, dump_pair_calls
+    from oracle_lib import Oracle
+    o = Oracle()
+    with tempfile.TemporaryDirectory() as work:
+        for call in dump_pair_calls(work):
+            o.render(call, interpolation=1)
+        pos1, pos2, dir1, dir2 = lrp.load_light_ray_data(work)
+        ipos, idir = lrp.load_intermediate_light_ray_data(work, DUMP_SLOTS)
+        d_pos, d_dir = lrp.calculate_lightray_deflections(pos1, pos2, dir1, dir2)
+    out = {}
+    for tag, dct in (("pos1", pos1), ("pos2", pos2), ("dir1", dir1), ("dir2", dir2), ("ipos", ipos), ("idir", idir),
+                     ("d_pos", d_pos), ("d_dir", d_dir)):
+        for k, v in dct.items():
+            out[f"{tag}_{k}"] = np.asarray(v)
+    lrp.np.reshape = numpy_reshape
+    np.savez_compressed(os.path.join(OUT, "dumps_reference_reader.npz"), **out)
+    print("dumps_reference_reader.npz:", {k: v.shape for k, v in out.items() if k.endswith("_x")})
+
+
 def main():
     sys.path.insert(0, os.path.join(REF, "python_codes"))
+    if "--dumps-only" in sys.argv:
+        dumps_golden()
+        return
 
     def shrink_piv(p):
         p["particle_field"]["particle_number"] = 300.0
@@ -384,6 +433,7 @@ def main():
     save_case("bos_im2", calls[1], post[1], params)
     lens_golden()
     pins_golden()
+    dumps_golden()
     # the sample cases at their REAL size (50 000 particles x 10 000 rays; the full dot grid x 500 rays): source arrays
     # + scalars only
     calls, post, params = run_case("piv", lambda p: p["particle_field"].__setitem__("frame_vector", np.array([1])))

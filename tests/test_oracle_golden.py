@@ -125,6 +125,24 @@ def test_constant_gradient_deflection(oracle, interp, algorithm):
     v.free()
 
 
+@pytest.mark.parametrize("interp", [1, 2])
+def test_bos_displacement_matches_the_paraxial_relation(oracle, tmp_path, interp):
+    """End to end -- march + lens + splat together: dots imaged through a constant-density-gradient volume move by
+    M * Z_D * epsilon / pixel_pitch pixels, the relation photon's own tooling uses to size its test volumes
+    (python_codes/nrrd_functions.py:60-82).  Measured 0.44 % off the paraxial prediction (thick lens, finite volume);
+    no shift across the gradient; the splat's x axis is flipped (.cu:1467)."""
+    from conftest import bos_displacement_case, image_centroid
+    c1, c2, predicted = bos_displacement_case(str(tmp_path))
+    im1, _ = oracle.render(c1)
+    im2, st = oracle.render(c2, interpolation=interp)
+    assert st.rk_iterations >= 60 * c2.num_rays                          # every ray crossed the whole 64^3 volume
+    (x1, y1), (x2, y2) = image_centroid(im1), image_centroid(im2)
+    assert abs(predicted - 3.0) < 1e-9
+    assert x2 - x1 < 0 and abs(abs(x2 - x1) - predicted) < 0.015 * predicted, (x2 - x1, predicted)
+    assert abs(y2 - y1) < 0.01
+    assert abs(im2.sum() / im1.sum() - 1) < 1e-3                          # the light is moved, not lost
+
+
 def test_tricubic_interpolates_at_the_knots(oracle):
     """prefilter o tricubic sampled at texel centres returns the samples
     (CubicInterpolationCUDA/examples/cudaAccuracyTest/cudaAccuracyTest_kernel.cu:79-100)."""
@@ -261,6 +279,46 @@ def test_intermediate_dumps_trace_the_march(oracle, tmp_path, algorithm):
     # cubic: nothing recorded
     oracle.render(call, interpolation=2)
     assert np.isnan(np.fromfile(tmp_path / "intermediate_pos_0000.bin", np.float32)).all()
+
+
+def check_dumps_against_reference_reader(folder, exact=True):
+    """Files under `folder` (layout of dump_pair_calls), parsed by OUR reading of the wire format, against what the
+    REFERENCE's reader (light_ray_processing.py:74-207, run in the build container by tests/golden/make_golden.py) made
+    of the oracle's files for the same calls: positions, arccos'd directions, intermediate [ray][slot] arrays and the
+    pos1 - pos2 / dir2 - dir1 deflections of calculate_lightray_deflections (:210-243)."""
+    from conftest import parse_dump_pair
+    ref = np.load(os.path.join(GOLDEN, "dumps_reference_reader.npz"))
+    got = parse_dump_pair(folder)
+    n = int(ref["pos1_num_rays"])
+    assert got["pos_im1"].shape == (n, 3) and got["ipos"].shape[0] == n and int(ref["ipos_num_rays"]) == n
+
+    def same(a, b, what):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        assert a.shape == b.shape, what
+        ok = (a == b) | (np.isnan(a) & np.isnan(b)) if exact else np.isclose(a, b, rtol=1e-6, atol=1e-6, equal_nan=True)
+        assert ok.all(), f"{what}: {np.count_nonzero(~ok)} of {ok.size} differ"
+
+    for axis, col in (("x", 0), ("y", 1), ("z", 2)):
+        same(got["pos_im1"][:, col], ref[f"pos1_{axis}"], f"pos1.{axis}")
+        same(got["pos_im2"][:, col], ref[f"pos2_{axis}"], f"pos2.{axis}")
+        same(got["ang_im1"][:, col], ref[f"dir1_{axis}"], f"dir1.{axis}")
+        same(got["ang_im2"][:, col], ref[f"dir2_{axis}"], f"dir2.{axis}")
+        same(got["ipos"][:, :, col], ref[f"ipos_{axis}"], f"ipos.{axis}")
+        same(got["iang"][:, :, col], ref[f"idir_{axis}"], f"idir.{axis}")
+        same(got["pos_im1"][:, col] - got["pos_im2"][:, col], ref[f"d_pos_{axis}"], f"d_pos.{axis}")
+        same(got["ang_im2"][:, col] - got["ang_im1"][:, col], ref[f"d_dir_{axis}"], f"d_dir.{axis}")
+    # and the data means something: the volume deflected the rays of image 2, the sensor hits moved
+    moved = np.nan_to_num(np.abs(ref["d_pos_x"])) + np.nan_to_num(np.abs(ref["d_pos_y"]))
+    assert np.count_nonzero(moved > 0) > n // 2
+
+
+def test_ray_dumps_as_the_reference_reader_sees_them(oracle, tmp_path):
+    """Wire-format pin for rows a1 / f4: what the oracle writes is what the reference's own reader parsed into the
+    committed fixture (same calls, regenerated here), read back with our understanding of the format."""
+    from conftest import dump_pair_calls
+    for call in dump_pair_calls(str(tmp_path)):
+        oracle.render(call, interpolation=1)
+    check_dumps_against_reference_reader(str(tmp_path))
 
 
 @pytest.mark.parametrize("algorithm", [3, 4])

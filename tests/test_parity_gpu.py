@@ -330,6 +330,36 @@ def test_ray_dumps_bit_exact(photon, oracle, small_volume_file, tmp_path):
     assert np.isfinite(np.fromfile(outs["gpu"][0] / "pos_0000.bin", np.float32)).any()
 
 
+@pytest.mark.parametrize("interp", [1, 2])
+def test_bos_displacement_matches_the_paraxial_relation(photon, oracle, tmp_path, monkeypatch, interp):
+    """End to end on the GPU, through start_ray_tracing: BOS dots rendered without and through a constant-density-gradient
+    volume; the centroid shift against photon's own relation displacement = M * Z_D * epsilon / pixel_pitch
+    (python_codes/nrrd_functions.py:60-82) -- march, lens and splat together -- and against the oracle's shift."""
+    from conftest import bos_displacement_case, image_centroid
+    monkeypatch.setenv("PHOTON_INTERP", "cubic" if interp == 2 else "linear")
+    c1, c2, predicted = bos_displacement_case(str(tmp_path))
+    im1, im2 = photon.render(c1), photon.render(c2)
+    (x1, y1), (x2, y2) = image_centroid(im1), image_centroid(im2)
+    assert x2 - x1 < 0 and abs(abs(x2 - x1) - predicted) < 0.015 * predicted, (x2 - x1, predicted)
+    assert abs(y2 - y1) < 0.01
+    o1, _ = oracle.render(c1)
+    o2, _ = oracle.render(c2, interpolation=interp)
+    assert abs((x2 - x1) - (image_centroid(o2)[0] - image_centroid(o1)[0])) < 1e-4
+    assert rel_l2(im2, o2) <= IMAGE_TOL
+
+
+def test_gpu_ray_dumps_as_the_reference_reader_sees_them(photon, tmp_path, monkeypatch):
+    """The GPU library's pos_/dir_/intermediate_*.bin for a BOS image pair, read with our understanding of the wire
+    format, against the arrays the REFERENCE's own reader (light_ray_processing.py:74-207) parsed from the oracle's files
+    for the same calls (tests/golden/dumps_reference_reader.npz, made in the build container): bit for bit."""
+    from conftest import dump_pair_calls
+    from test_oracle_golden import check_dumps_against_reference_reader
+    monkeypatch.setenv("PHOTON_INTERP", "linear")
+    for call in dump_pair_calls(str(tmp_path)):
+        photon.render(call)
+    check_dumps_against_reference_reader(str(tmp_path))
+
+
 @pytest.mark.parametrize("algorithm", [1, 2])
 def test_intermediate_ray_dumps_bit_exact(photon, oracle, small_volume_file, tmp_path, monkeypatch, algorithm):
     """save_intermediate_ray_data: position / direction at the start of the first N march iterations
@@ -840,10 +870,11 @@ def test_c2_full_size_against_oracle(photon, oracle):
 # ------------------------------------------------------------------------------------------------
 # BASELINE-size properties (no oracle: size-independent invariants)
 # ------------------------------------------------------------------------------------------------
-def test_full_size_c3_properties(photon, workdir, monkeypatch):
+def test_full_size_c3_properties(photon, oracle, workdir, monkeypatch):
     """1e7 rays through the 256^3 volume (tricubic RK4): (1) sharding the sources in two and
     summing reproduces the single-pass image (what the multi-GPU path relies on); (2) a uniform
-    volume deflects nothing: the image equals the no-volume image; (3) counters add up."""
+    volume deflects nothing: the image equals the no-volume image; (3) counters add up; (4) a 40-source slice of the
+    job equals the oracle's render of those sources through the same 256^3 volume."""
     import torch
     monkeypatch.setenv("PHOTON_INTERP", "cubic")
     call = scenes.config("C3", workdir)
@@ -856,6 +887,16 @@ def test_full_size_c3_properties(photon, workdir, monkeypatch):
     assert st.rays_launched == call.num_rays
     assert st.rk_iterations >= 250 * call.num_rays and st.volume_samples >= 3 * st.rk_iterations
     assert st.rays_on_sensor == call.num_rays and st.sensor_taps > 10 * call.num_rays
+    # a 40-source slice of the same 256^3 tricubic job against the oracle (the oracle needs ~1 s for it)
+    sl = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    scene.trace(sl.data_ptr(), vol, 2, 0, 40)
+    torch.cuda.synchronize()
+    head = scenes.config("C3", workdir)
+    for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+        setattr(head, f, getattr(head, f)[:40])
+    ref, ost = oracle.render(head, interpolation=2)
+    assert ost.rk_iterations >= 250 * head.num_rays
+    assert rel_l2(sl.cpu().numpy().reshape(H, W), ref) <= IMAGE_TOL
     halves = torch.zeros(H * W, dtype=torch.float32, device="cuda")
     mid = call.num_sources // 2 + 7
     scene.trace(halves.data_ptr(), vol, 2, 0, mid)
@@ -907,6 +948,47 @@ def test_c4_one_gpu_share_properties(photon, workdir, monkeypatch):
         vol.free()
     assert 0 < rel_l2(images[1], images[2]) < 2e-2
     scene.free()
+
+
+def test_c4_whole_job_on_one_gpu(photon, oracle, workdir, monkeypatch):
+    """BASELINE config C4 WHOLE: 2e5 sources x 500 = 1e8 rays through the 512^3 volume (tricubic RK4) on one GPU -- the
+    multi-launch loop WITH a volume (two launches of <= 2^26 rays; the reference chunks at 10^4 sources,
+    parallel_ray_tracing.cu:3366-3372, 3515-3558): (1) device-resident photon_trace: every ray crosses the grid (>= 509
+    iterations) and lands; (2) the same job through start_ray_tracing (host arrays in, host image out) gives the same
+    image; (3) so do eight shards side by side (PHOTON_DEVICES=0 x 8: the per-device upload / accumulate / sum path);
+    (4) a 20-source slice equals the oracle's render through the same 512^3 volume."""
+    import torch
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    call = scenes.config("C4", workdir, volume_n=512)
+    assert call.num_rays == 100_000_000 and call.num_sources == 200_000
+    H, W = call.image_shape
+    scene = photon.scene_create(call)
+    vol = photon.volume_load_nrrd(call.density_grad_filename, 2)
+    img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    st = scene.trace(img.data_ptr(), vol, 2, want_stats=True)
+    assert st.rays_launched == call.num_rays and st.rays_on_sensor == call.num_rays and st.rays_marched == call.num_rays
+    assert st.rk_iterations >= 509 * call.num_rays
+    whole = img.cpu().numpy().reshape(H, W)
+    sl = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    scene.trace(sl.data_ptr(), vol, 2, 0, 20)
+    torch.cuda.synchronize()
+    slice_gpu = sl.cpu().numpy().reshape(H, W)
+    scene.free()
+    vol.free()
+    del img, sl
+    torch.cuda.empty_cache()
+    abi = photon.render(call)                                          # the reference's entry point, two launches
+    assert rel_l2(abi, whole) <= IMAGE_TOL
+    monkeypatch.setenv("PHOTON_DEVICES", "0,0,0,0,0,0,0,0")
+    shards = photon.render(call)
+    monkeypatch.delenv("PHOTON_DEVICES")
+    assert rel_l2(shards, whole) <= IMAGE_TOL
+    head = scenes.config("C4", workdir, volume_n=512)
+    for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+        setattr(head, f, getattr(head, f)[:20])
+    ref, ost = oracle.render(head, interpolation=2)
+    assert ost.rk_iterations >= 509 * head.num_rays
+    assert rel_l2(slice_gpu, ref) <= IMAGE_TOL
 
 
 @pytest.mark.parametrize("case", ["piv", "bos_im1", "bos_im2"])

@@ -7,7 +7,7 @@ import sys
 import tempfile
 import time
 
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402  (first: one HIP runtime per process)
 from photon_amd import scenes  # noqa: E402
 from photon_amd.library import PhotonLibrary  # noqa: E402

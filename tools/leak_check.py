@@ -1,5 +1,5 @@
 import os, sys, tempfile
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from photon_amd import scenes
 from photon_amd.library import PhotonLibrary

@@ -1,18 +1,36 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/: kernel stats of the default bench command, then PMC passes
-# (each counter set in its own run, no tracing alongside).   tools/profile_round.sh <tag>
+# rocprofv3 evidence for profiles/<tag>_*: per workload one kernel-trace pass and four PMC passes (each counter set in its
+# own run, no tracing alongside).      tools/profile_round.sh <tag> [workload ...]
+#   workloads: cubic (C3 headline), linear (C3, the reference's sampler), euler_cubic, euler_linear, c5 (incoherent launch,
+#              1/4 size), tail (one GPU's eighth of C3: bench.py --dots 25), c4 (the whole 1e8-ray 512^3 job, kernel stats only)
 set -e
-tag=${1:-rXX}
-out=$PWD/gpurun_out/prof_$tag
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+tag=${1:-r03}; shift || true
+wl=("$@"); [ ${#wl[@]} -eq 0 ] && wl=(cubic linear euler_cubic euler_linear c5)
+out=$ROOT/gpurun_out/prof_$tag
 mkdir -p "$out"
-cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample-rays 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- python3 $B > "$out/bench_stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o fetch -- python3 $B > "$out/bench_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o write -- python3 $B > "$out/bench_write.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$out/valu" -o valu -- python3 $B > "$out/bench_valu.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU --output-format csv -d "$out/lds" -o lds -- python3 $B > "$out/bench_lds.log" 2>&1
-cd "$GRAFT_REPO_ROOT"
-python3 tools/pmc_summary.py "$out/fetch" "$out/write" march_cubic_256 "$out/pmc_summary.json"
-find "$out" -name "*_kernel_stats.csv" | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
-ls "$out"
+export TMPDIR=/tmp
+B="$ROOT/bench.py --steps 3 --warmup 1 --cpu-sample-rays 0 --no-traffic"
+for w in "${wl[@]}"; do
+  pmc=1
+  case $w in
+    cubic) cmd="$B" ;;
+    linear) cmd="$B --interp linear" ;;
+    euler_cubic) cmd="$B --algorithm 1" ;;
+    euler_linear) cmd="$B --algorithm 1 --interp linear" ;;
+    tail) cmd="$B --dots 25" ;;
+    c4) cmd="$B --volume 512 --dots 2000"; pmc=0 ;;
+    c5) cmd="$ROOT/tools/c5_full.py 0.25" ;;
+    *) echo "unknown workload $w"; exit 1 ;;
+  esac
+  d="$out/$w"; mkdir -p "$d"
+  echo "== $w: $cmd"
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$d/stats" -o s -- python3 $cmd > "$d/stats.log" 2>&1)
+  [ $pmc = 1 ] || continue
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+    n=$(echo $set | cut -d' ' -f1)
+    (cd /tmp && rocprofv3 --pmc $set --output-format csv -d "$d/pmc_$n" -o p -- python3 $cmd > "$d/pmc_$n.log" 2>&1)
+  done
+done
+cd "$ROOT"
+python3 tools/profile_round_summary.py "$out" "$tag"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Condense tools/profile_r02.sh output into profiles/: per workload the kernel stats CSV (photon kernels only) and one
-JSON with the per-launch PMC means of the march / sensor / splat kernels.   profile_r02_summary.py <dir> <tag>"""
+"""Condense tools/profile_round.sh output into profiles/: per workload the kernel stats CSV (photon kernels only) and one
+JSON with the per-launch PMC means of the march / sensor / splat kernels.   profile_round_summary.py <dir> <tag>"""
 import collections
 import csv
 import glob
