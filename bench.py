@@ -355,7 +355,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    march_ms, iters, samples, taps, on_sensor, marched, clock_mhz = 0.0, 0, 0, 0, 0, 0, 0.0
+    march_ms, iters, samples, taps, on_sensor, marched, clock_mhz, wave_ms = 0.0, 0, 0, 0, 0, 0, 0.0, 0.0
     for _ in range(args.steps):
         st = step(not windowed)       # HIP events bracket the march kernel on the launch stream
         if not windowed:              # (a library without the statistics window: per-step stats, one host sync per step)
@@ -374,6 +374,7 @@ def main():
         iters, samples, taps = st.rk_iterations // k, st.volume_samples // k, st.sensor_taps // k
         on_sensor, marched = st.rays_on_sensor // k, st.rays_marched // k
         clock_mhz = float(st.shader_clock_mhz)
+        wave_ms = float(st.march_wave_ms)
     rays_rank = (src_end - src_begin) * args.rays_per_source
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
@@ -409,6 +410,8 @@ def main():
     roofline = {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / LDS_PEAK_GBS, 4), "traffic": None,
                 "clock_mhz": round(clock_mhz, 1) if clock_mhz > 0 else None,
+                "wave_lifetime_ms": round(wave_ms, 4) if wave_ms > 0 else None,
+                "wave_generations": round(rays_rank / 64 / (256 * 4 * 5), 2),
                 "peak_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
                 "frac_at_clock": round(achieved / peak_at_clock, 4) if peak_at_clock else None,
                 "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),

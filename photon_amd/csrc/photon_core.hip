@@ -126,8 +126,13 @@ __device__ __forceinline__ unsigned long long *counter_slot(unsigned long long *
 #ifndef PHOTON_XCD_CHUNK
 #define PHOTON_XCD_CHUNK 32
 #endif
+#ifndef PHOTON_MARCH_BLOCK
+#define PHOTON_MARCH_BLOCK_FOR_REMAP 256
+#else
+#define PHOTON_MARCH_BLOCK_FOR_REMAP PHOTON_MARCH_BLOCK
+#endif
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
-    constexpr unsigned B = PHOTON_XCD_CHUNK;
+    constexpr unsigned B = PHOTON_XCD_CHUNK * (256 / PHOTON_MARCH_BLOCK_FOR_REMAP);
     const unsigned full = nb / (8u * B) * (8u * B);            // blocks that form complete rounds of 8 chunks
     if (bid >= full) return bid;
     const unsigned xcd = bid & 7u, q = bid >> 3;                // q-th block this XCD receives
@@ -419,11 +424,14 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk), "=s"(real) : : "memory");
 }
 
+#ifndef PHOTON_MARCH_BLOCK
+#define PHOTON_MARCH_BLOCK 256          // threads per workgroup of the march (a multiple of 64)
+#endif
 template <int ALGO, int INTERP, bool SAVE, bool NOISE>
-__global__ __launch_bounds__(256, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
+__global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
                                                        RayStateDev st, unsigned long long *__restrict__ counters,
                                                        NoiseDev noise, unsigned long long ray_base, InterDump idump) {
-    __shared__ f4 tiles[4][kWaveLdsTexels];                     // per wave: 4x4x4 tile + 8x8x4 brick, rows padded (device_volume_coop.hpp)
+    __shared__ f4 tiles[PHOTON_MARCH_BLOCK / 64][kWaveLdsTexels];                     // per wave: 4x4x4 tile + 8x8x4 brick, rows padded (device_volume_coop.hpp)
     unsigned long long clk0, real0, clk1, real1;
     clock_stamp(clk0, real0);
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1565,7 +1573,8 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         const unsigned long long ray_base = (unsigned long long)(s->dev.source_base + src_begin) * (unsigned)s->dev.rays_per_source;
         const InterDump idump{dump.inter_pos, dump.inter_dir, dump.inter_slots, dump.num_save, 0u};
         const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
-#define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), grid, block, 0, stream, vol->dev, tex, n, s->ws, \
+        const dim3 mblock(PHOTON_MARCH_BLOCK), mgrid((n + PHOTON_MARCH_BLOCK - 1) / PHOTON_MARCH_BLOCK);
+#define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), mgrid, mblock, 0, stream, vol->dev, tex, n, s->ws, \
                                                 s->d_counters, s->dev.noise, ray_base, idump)
         if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
@@ -1662,6 +1671,8 @@ static int read_counters(photon_scene *scene, bool have_volume, photon_trace_sta
     stats->rays_marched = have_volume ? c[CNT_MARCHED] : 0;
     // s_memtime ticks per s_memrealtime tick (100 MHz), over all waves of the march: the clock the kernel ran at
     stats->shader_clock_mhz = c[CNT_REAL] ? (float)((double)c[CNT_CLK] / (double)c[CNT_REAL] * 100.0) : 0.f;
+    // mean lifetime of a march wave (64 rays): with 5 waves per SIMD a launch lasts about (waves / 5120) lifetimes
+    stats->march_wave_ms = c[CNT_MARCHED] ? (float)((double)c[CNT_REAL] * 1e-5 / ((double)(c[CNT_MARCHED] + 63) / 64.0)) : 0.f;
     return 0;
 }
 

@@ -41,7 +41,8 @@ class photon_trace_stats_t(ctypes.Structure):
     _fields_ = [("rays_launched", ctypes.c_uint64), ("rays_on_sensor", ctypes.c_uint64),
                 ("rk_iterations", ctypes.c_uint64), ("volume_samples", ctypes.c_uint64),
                 ("sensor_taps", ctypes.c_uint64), ("march_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("rays_marched", ctypes.c_uint64), ("shader_clock_mhz", ctypes.c_float), ("traces", ctypes.c_uint32)]
+                ("rays_marched", ctypes.c_uint64), ("shader_clock_mhz", ctypes.c_float), ("traces", ctypes.c_uint32),
+                ("march_wave_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
