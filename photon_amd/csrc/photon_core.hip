@@ -427,44 +427,126 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 #ifndef PHOTON_MARCH_BLOCK
 #define PHOTON_MARCH_BLOCK 256          // threads per workgroup of the march (a multiple of 64)
 #endif
+// PERSISTENT WAVES (round 3).  Every ray of a BOS launch marches for the same ~1.8 ms, so the waves of a conventional
+// launch finish generation by generation, and each time the dispatcher has a whole chip's worth of workgroups to start at
+// once: measured on C3, the resident-wave slots stood empty 7.5 % of the kernel's time (156 250 waves x 1.76 ms mean
+// lifetime / 5120 slots = 53.9 ms of work in a 58.2 ms kernel; the same 7.7 % on the 1.2 s C4 launch, and a launch of G
+// generations lasted about G + 0.9 lifetimes -- one GPU's eighth of C3, 3.8 generations, ran at 81 % occupancy).
+// Here the grid is just large enough to fill the chip ONCE and every wave takes 64-ray groups from a queue until the
+// launch is served: a wave that finishes a group loads the next one itself, no slot waits for the dispatcher.
+// One queue per XCD (workgroup i runs on XCD i % 8): a queue hands out the groups of every eighth 8K-ray chunk in
+// order, so rays that walk the same voxels still meet in one L2 (what xcd_remap did for the one-shot launch); a wave
+// whose own queue is empty serves the others' leftovers, so the launch ends without a straggling XCD.  Every wave
+// leaves as soon as all eight queues are past their ends.
+#ifndef PHOTON_MARCH_PERSISTENT
+#define PHOTON_MARCH_PERSISTENT 1
+#endif
+constexpr unsigned kQueueStride = 16;                           // u32 per queue counter: one 64-byte line each
+[[maybe_unused]] constexpr unsigned kGroupsPerChunk = PHOTON_XCD_CHUNK * 4;      // 64-ray groups per 8K-ray chunk
+
+// The march kernel's arguments, read from the kernel-argument segment WHERE THEY ARE USED (scalar loads through a pointer
+// the optimiser cannot see through) instead of being held in SGPRs from the prologue on: the persistent loop needs them
+// again for every group, and ~55 argument SGPRs live across the march loop -- whose own constants, masks and tile ids take
+// ~60 -- overflowed the 102 a wave has (15-55 SGPRs spilled into VGPR lanes, and VGPRs into scratch).
+struct MarchArgs {
+    VolumeDev vol;
+    const f4 *tex;
+    unsigned n_rays;
+    RayStateDev st;
+    unsigned long long *counters;
+    NoiseDev noise;
+    unsigned long long ray_base;
+    InterDump idump;
+    unsigned *queue;
+};
+typedef const __attribute__((address_space(4))) MarchArgs *MarchArgsPtr;
+template <class T>
+__device__ __forceinline__ T load_arg(const __attribute__((address_space(4))) T *p) {      // scalar loads from the argument segment
+    T out;
+    __builtin_memcpy(&out, p, sizeof(T));
+    return out;
+}
+__device__ __forceinline__ MarchArgsPtr march_args() {
+    MarchArgsPtr p = (MarchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                                 // a fresh pointer each time: loads through it are neither hoisted nor kept
+    return p;
+}
+
 template <int ALGO, int INTERP, bool SAVE, bool NOISE>
-__global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(VolumeDev vol, const f4 *__restrict__ tex, unsigned n_rays,
-                                                       RayStateDev st, unsigned long long *__restrict__ counters,
-                                                       NoiseDev noise, unsigned long long ray_base, InterDump idump) {
+__global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(MarchArgs) {
     __shared__ f4 tiles[PHOTON_MARCH_BLOCK / 64][kWaveLdsTexels];                     // per wave: 4x4x4 tile + 8x8x4 brick, rows padded (device_volume_coop.hpp)
-    unsigned long long clk0, real0, clk1, real1;
-    clock_stamp(clk0, real0);
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned r = bid * blockDim.x + threadIdx.x;
-    const bool has_ray = r < n_rays;
-    WaveCount mc{0u, 0u};                                       // wave-uniform totals (SGPRs)
-    f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
-    bool marching = has_ray;
-    if (has_ray) {
-        p = mk3(st.px[r], st.py[r], st.pz[r]);
-        d = mk3(st.dx[r], st.dy[r], st.dz[r]);
-        marching = !isnan3(p);                                  // rays marked dead by raygen_kernel stay out of the march
+    const unsigned lane = threadIdx.x & 63u;
+    WaveCount mc{0u, 0u};                                       // wave-uniform totals (SGPRs), over all groups of this wave
+    unsigned n_marched = 0;
+    unsigned long long clk_sum = 0, real_sum = 0;
+#if PHOTON_MARCH_PERSISTENT
+    const unsigned home = blockIdx.x & 7u;
+    for (unsigned q = 0; q < 8u; q++) {
+        const unsigned x = (home + q) & 7u;                     // own XCD's queue first, then the others' leftovers
+        while (true) {
+            unsigned k = 0;
+            MarchArgsPtr a = march_args();
+            const unsigned n_rays = a->n_rays;
+            if (lane == 0) k = atomicAdd(&a->queue[x * kQueueStride], 1u);
+            k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+            const unsigned group = ((k / kGroupsPerChunk) * 8u + x) * kGroupsPerChunk + k % kGroupsPerChunk;
+            if (group >= (n_rays + 63u) / 64u) break;           // groups grow with k: this queue is served
+#else
+    {
+        {
+            MarchArgsPtr a = march_args();
+            const unsigned n_rays = a->n_rays;
+            const unsigned group = xcd_remap(blockIdx.x, gridDim.x) * (PHOTON_MARCH_BLOCK / 64) + (threadIdx.x >> 6);
+            if (group < (n_rays + 63u) / 64u) {
+#endif
+            unsigned long long clk0, real0, clk1, real1;
+            clock_stamp(clk0, real0);
+            const unsigned r = group * 64u + lane;
+            const bool has_ray = r < n_rays;
+            f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
+            bool marching = has_ray;
+            {
+                const RayStateDev st = load_arg(&a->st);
+                if (has_ray) {
+                    p = mk3(st.px[r], st.py[r], st.pz[r]);
+                    d = mk3(st.dx[r], st.dy[r], st.dz[r]);
+                    marching = !isnan3(p);                      // rays marked dead by raygen_kernel stay out of the march
+                }
+            }
+            const unsigned group_marched = (unsigned)__popcll(ballot(marching));   // rays that enter the march (not skipped as doomed)
+            const VolumeDev vol = load_arg(&a->vol);
+            const f4 *tex = a->tex;
+            GradNoise gn{0, 0.f, 0ull, 0ull};
+            if (NOISE) { const NoiseDev nz = load_arg(&a->noise); gn = GradNoise{nz.add_ngrad, nz.ngrad_std, nz.seed, a->ray_base + r}; }
+            InterDump idump{nullptr, nullptr, 0, 0, 0u};
+            if (SAVE) idump = load_arg(&a->idump);
+            idump.ray = r;                                      // chunk-global ray id, like the final dumps
+            if (INTERP == 1 && vol.weight_scale > 0.f)          // kernel-uniform: the texture unit's 8-bit weights (the default) / exact f32
+                trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
+            else
+                trace_volume_coop<ALGO, INTERP, SAVE, NOISE, false, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);
+            {
+                const RayStateDev st = load_arg(&march_args()->st);        // loaded again: not carried through the march in SGPRs
+                if (marching) {
+                    st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
+                    st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+                }
+            }
+            clock_stamp(clk1, real1);
+            if (group_marched) { n_marched += group_marched; clk_sum += clk1 - clk0; real_sum += real1 - real0; }
+#if !PHOTON_MARCH_PERSISTENT
+            }
+#endif
+        }
     }
-    const unsigned n_marched = (unsigned)__popcll(ballot(marching));       // rays that enter the march (not skipped as doomed)
-    const GradNoise gn{noise.add_ngrad, noise.ngrad_std, noise.seed, ray_base + r};
-    idump.ray = r;                                              // chunk-global ray id, like the final dumps
-    if (INTERP == 1 && vol.weight_scale > 0.f)                  // kernel-uniform: the texture unit's 8-bit weights (the default) / exact f32
-        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
-    else
-        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, false, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);
-    if (marching) {
-        st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
-        st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
-    }
-    clock_stamp(clk1, real1);
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long *slot = counter_slot(counters);
+    if (lane == 0) {
+        unsigned long long *slot = counter_slot(march_args()->counters);
         if (mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)mc.iterations);
         if (mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)mc.samples);
         if (n_marched) {
             atomicAdd(&slot[CNT_MARCHED], (unsigned long long)n_marched);
-            atomicAdd(&slot[CNT_CLK], clk1 - clk0);
-            atomicAdd(&slot[CNT_REAL], real1 - real0);
+            atomicAdd(&slot[CNT_CLK], clk_sum);
+            atomicAdd(&slot[CNT_REAL], real_sum);
         }
     }
 }
@@ -715,6 +797,8 @@ struct photon_scene {
     RayStateDev ws{};                   // march -> sensor state, grown on demand
     size_t ws_rays = 0;
     unsigned long long *d_counters = nullptr;
+    unsigned *d_queue = nullptr;        // the march's work queues: one counter per XCD, a cache line apart
+    int num_cus = 256;                  // compute units of the scene's device (size of the persistent march grid)
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // statistics window (photon_scene_stats_begin / _end): traces inside it record their events and leave the counters
@@ -1132,6 +1216,7 @@ void photon_scene_free(photon_scene_t *s) {
     if (s->ws.px) (void)hipFree(s->ws.px);
     if (s->ws.radiance) (void)hipFree(s->ws.radiance);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_acc) (void)hipFree(s->d_acc);
     for (auto &p : s->perms) if (p.d_perm) (void)hipFree(p.d_perm);
     photon_sort_scratch_free(&s->sort_scratch);
@@ -1382,6 +1467,13 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     e = hipMalloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    e = hipMalloc((void **)&s->d_queue, 8 * kQueueStride * sizeof(unsigned));
+    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            s->num_cus = cus;
+    }
     for (auto &ev : s->ev) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { fprintf(stderr, "photon: hipEventCreate failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
@@ -1567,15 +1659,20 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         if (rc) return rc;
         hipLaunchKernelGGL(raygen_kernel, grid, block, 0, stream, s->dev, src_begin, n, s->ws);
         PH_CHECK(hipGetLastError());
-        if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
         const int interp = vol->dev.interpolation;
         const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
         const unsigned long long ray_base = (unsigned long long)(s->dev.source_base + src_begin) * (unsigned)s->dev.rays_per_source;
         const InterDump idump{dump.inter_pos, dump.inter_dir, dump.inter_slots, dump.num_save, 0u};
         const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
-        const dim3 mblock(PHOTON_MARCH_BLOCK), mgrid((n + PHOTON_MARCH_BLOCK - 1) / PHOTON_MARCH_BLOCK);
-#define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), mgrid, mblock, 0, stream, vol->dev, tex, n, s->ws, \
-                                                s->d_counters, s->dev.noise, ray_base, idump)
+        // persistent waves: a grid that fills the chip once (more workgroups than fit only find empty queues and leave)
+        const unsigned all_blocks = (n + PHOTON_MARCH_BLOCK - 1) / PHOTON_MARCH_BLOCK;
+        const unsigned fill_blocks = (unsigned)s->num_cus * 8u * (256 / PHOTON_MARCH_BLOCK);
+        const dim3 mblock(PHOTON_MARCH_BLOCK), mgrid(PHOTON_MARCH_PERSISTENT ? std::min(all_blocks, fill_blocks) : all_blocks);
+        if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2))
+            PH_CHECK(hipMemsetAsync(s->d_queue, 0, 8 * kQueueStride * sizeof(unsigned), stream));
+        if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
+        const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue};
+#define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), mgrid, mblock, 0, stream, margs)
         if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm != 1 && algorithm != 2) hipLaunchKernelGGL((march_extra_kernel<0>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
