@@ -320,8 +320,16 @@ def main():
     # strong: every rank holds the ONE job's scene and traces its shard_range of the sources;
     # weak:   every rank has its own scene (different dots) and traces all of it
     call = make_call(seed=1 if strong else 1 + rank)
+    job_sources = call.num_sources
     src_begin, src_end = shard_range(call.num_sources, rank, world) if strong else (0, call.num_sources)
+    if strong and world > 1:
+        # each rank uploads ONLY its shard of the job's source list (what render_on_devices does inside the library)
+        for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+            setattr(call, f, getattr(call, f)[src_begin:src_end])
     scene = lib.scene_create(call)
+    if strong and world > 1:
+        scene.set_source_base(src_begin)            # noise ids (unused here) stay those of the whole job
+        src_begin, src_end = 0, call.num_sources
     t0 = time.perf_counter()
     volume = lib.volume_load_nrrd(vol_path, interp)
     torch.cuda.synchronize()
@@ -397,7 +405,7 @@ def main():
     flops_per_sample = {"linear": 100.0, "cubic": 570.0}[args.interp]
     flops = samples * flops_per_sample + iters * 120.0
     tflops = flops / (march_ms_avg * 1e-3) * 1e-12 if march_ms_avg > 0 else 0.0
-    compulsory = int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources)
+    compulsory = int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources)       # SURVEY.md 8d (this rank)
     # The march serves its texels from LDS: a wave fetches each block once and every lane reads it back with
     # broadcast ds_read_b128, so the ALGORITHMIC bytes of SURVEY 8d (S x 3 x T x 16 per ray) are exactly the bytes
     # the kernel pulls through the LDS read pipe; they never were HBM bytes.  The bound that prices them is the LDS
@@ -441,7 +449,7 @@ def main():
                 gbs = traffic / (march_ms_avg * 1e-3) * 1e-9
                 roofline["hbm"]["traffic_gbs"] = round(gbs, 1)
                 roofline["hbm"]["frac"] = round(gbs / HBM_PEAK_GBS, 4)
-        desc = (f"C3: BOS, {total_rays} rays ({call.num_sources} sources x {args.rays_per_source}"
+        desc = (f"C3: BOS, {total_rays} rays ({job_sources} sources x {args.rays_per_source}"
                 f"{' per GPU' if not strong and world > 1 else ''}), {args.volume}^3 volume, "
                 f"{'RK4' if args.algorithm == 2 else 'Euler'}, {args.interp} sampler, "
                 f"erf splat D=3, 1024^2 sensor")
@@ -473,7 +481,7 @@ def main():
                 from oracle_lib import Oracle
                 ref, _ = Oracle().render(make_call(seed=1), interpolation=interp)
                 got = image.cpu().numpy().reshape(H, W).astype(np.float64)
-                out["check"] = {"rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "sources": call.num_sources,
+                out["check"] = {"rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "sources": job_sources,
                                 "what": "reduced image of all ranks vs the oracle's render of the whole job"}
         elif args.check:
             out["check"] = check_against_oracle(lib, make_call, vol_path, interp)

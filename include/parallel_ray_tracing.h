@@ -261,6 +261,11 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
  * start_ray_tracing reads it from PHOTON_ELEMENT_TRAIN=reference|sequential. */
 int photon_scene_set_element_train(photon_scene_t *scene, int mode);
 
+/* A scene that holds only a SLICE of a job's source list (one rank of a multi-GPU job uploads just its shard): the
+ * index, in the job's list, of this scene's first source.  Only the noise hooks read it -- their generator is keyed by the
+ * ray's place in the whole job, so a sharded render draws the numbers the unsharded one draws.  Default 0. */
+int photon_scene_set_source_base(photon_scene_t *scene, int64_t first_source);
+
 /* Order in which a launch lays its rays over the GPU's lanes (results are a sum: the image does not depend
  * on it beyond f64 summation order).  0 = source-major, the reference's thread order (.cu:1988-2006): best
  * when a source's ray cone is narrower than a volume texel (BOS).  1 = lens-major over spatially sorted

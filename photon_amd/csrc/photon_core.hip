@@ -481,19 +481,28 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
     unsigned long long clk_sum = 0, real_sum = 0;
 #if PHOTON_MARCH_PERSISTENT
     const unsigned home = blockIdx.x & 7u;
+    // Groups per queue access: 1 while groups are real work (~1.8 ms each: the finest balance at the end of the launch),
+    // doubling up to 64 while they are trivial -- a launch whose rays all miss the volume (the reference's sample BOS case)
+    // would otherwise spend its time on ~1e6 returning atomics to eight addresses.
+    unsigned batch = 1;
     for (unsigned q = 0; q < 8u; q++) {
         const unsigned x = (home + q) & 7u;                     // own XCD's queue first, then the others' leftovers
-        while (true) {
-            unsigned k = 0;
+        bool served = false;
+        while (!served) {
+            unsigned k0 = 0;
+            if (lane == 0) k0 = atomicAdd(&march_args()->queue[x * kQueueStride], batch);
+            k0 = (unsigned)__builtin_amdgcn_readfirstlane((int)k0);
+            unsigned long long last_cycles = 0;
+            for (unsigned i = 0; i < batch; i++) {
+            const unsigned k = k0 + i;
             MarchArgsPtr a = march_args();
             const unsigned n_rays = a->n_rays;
-            if (lane == 0) k = atomicAdd(&a->queue[x * kQueueStride], 1u);
-            k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             const unsigned group = ((k / kGroupsPerChunk) * 8u + x) * kGroupsPerChunk + k % kGroupsPerChunk;
-            if (group >= (n_rays + 63u) / 64u) break;           // groups grow with k: this queue is served
+            if (group >= (n_rays + 63u) / 64u) { served = true; break; }      // groups grow with k: this queue is served
 #else
     {
         {
+            {
             MarchArgsPtr a = march_args();
             const unsigned n_rays = a->n_rays;
             const unsigned group = xcd_remap(blockIdx.x, gridDim.x) * (PHOTON_MARCH_BLOCK / 64) + (threadIdx.x >> 6);
@@ -534,7 +543,12 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
             }
             clock_stamp(clk1, real1);
             if (group_marched) { n_marched += group_marched; clk_sum += clk1 - clk0; real_sum += real1 - real0; }
-#if !PHOTON_MARCH_PERSISTENT
+#if PHOTON_MARCH_PERSISTENT
+            last_cycles = clk1 - clk0;
+            }
+            batch = last_cycles < 50000ull ? (batch < 64u ? batch * 2u : 64u) : 1u;     // ~20 us of shader clock
+#else
+            }
             }
 #endif
         }
@@ -1487,6 +1501,12 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
     if (!scene) return 1;
     scene->dev.noise = NoiseDev{add_pos_noise ? 1 : 0, add_ngrad_noise ? 1 : 0, pos_noise_std, ngrad_noise_std,
                                 (unsigned long long)seed};
+    return 0;
+}
+
+int photon_scene_set_source_base(photon_scene_t *s, int64_t first_source) {
+    if (!s || first_source < 0) return 1;
+    s->dev.source_base = (long long)first_source;
     return 0;
 }
 

@@ -20,7 +20,7 @@ from .ray_tracing import (RayTracingCall, bind_start_ray_tracing, camera_design_
 DECLARED_SYMBOLS = (
     "start_ray_tracing", "photon_set_device", "photon_rand_table", "photon_volume_load_nrrd",
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
-    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_trace",
+    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_trace",
     "photon_scene_stats_begin", "photon_scene_stats_end", "photon_trace_volume_rays", "photon_version",
     # section 3: scene generation on the device
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
@@ -137,6 +137,8 @@ class PhotonLibrary:
         L.photon_scene_set_element_train.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.photon_scene_set_ray_order.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.photon_scene_set_skip_doomed.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        if hasattr(L, "photon_scene_set_source_base"):
+            L.photon_scene_set_source_base.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         L.photon_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(photon_trace_stats_t)]
         self.has_stats_window = hasattr(L, "photon_scene_stats_begin")     # absent from libraries built before round 3 (A/B runs)
@@ -418,6 +420,10 @@ class Scene:
     def set_skip_doomed(self, on: bool):
         """Drop rays that provably die on the first element's aperture before the march (default on)."""
         self._lib._check(self._lib.lib.photon_scene_set_skip_doomed(self.handle, int(bool(on))), "photon_scene_set_skip_doomed")
+
+    def set_source_base(self, first_source: int):
+        """This scene holds the slice of a job's sources that starts at `first_source` (noise ids stay job-wide)."""
+        self._lib._check(self._lib.lib.photon_scene_set_source_base(self.handle, int(first_source)), "photon_scene_set_source_base")
 
     def set_element_train(self, mode: int):
         """0 = the reference's element walk (element 0 only), 1 = the working multi-element train."""

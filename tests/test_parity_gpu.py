@@ -413,6 +413,43 @@ def test_position_noise_hook(photon, oracle, monkeypatch):
     oracle.set_noise_seed(0)
 
 
+def test_scene_slices_keep_job_wide_noise_ids(photon, small_volume_file):
+    """photon_scene_set_source_base: a scene that holds only a slice of the job's sources (one rank of a sharded job)
+    draws the noise the whole-job scene draws for those rays -- position noise in the sensor stage, gradient noise in
+    the Euler march -- so the sum of the slices is the whole render."""
+    import copy
+    import torch
+    call = scenes.bos_scene(n_dots=4, points_per_dot=15, rays_per_source=64, density_grad_filename=small_volume_file,
+                            ray_tracing_algorithm=1)
+    H, W = call.image_shape
+    vol = photon.volume_load_nrrd(small_volume_file, 1)
+
+    def render(c, base, n):
+        sc = photon.scene_create(c)
+        sc.set_noise(add_pos_noise=True, pos_noise_std=0.4, add_ngrad_noise=True, ngrad_noise_std=2e-8, seed=31)
+        sc.set_source_base(base)
+        img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+        sc.trace(img.data_ptr(), vol, 1, 0, n)
+        torch.cuda.synchronize()
+        sc.free()
+        return img.cpu().numpy().astype(np.float64)
+
+    whole = render(call, 0, call.num_sources)
+    cut = 23
+    parts = np.zeros_like(whole)
+    for lo, hi in ((0, cut), (cut, call.num_sources)):
+        c = copy.copy(call)
+        for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+            setattr(c, f, getattr(call, f)[lo:hi])
+        parts += render(c, lo, hi - lo)
+    assert rel_l2(parts, whole) <= 1e-6
+    c = copy.copy(call)                                                  # and without the base the second slice draws other numbers
+    for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+        setattr(c, f, getattr(call, f)[cut:])
+    assert rel_l2(render(c, 0, call.num_sources - cut) + render(call, 0, cut), whole) > 1e-3
+    vol.free()
+
+
 def test_gradient_noise_hook(photon, oracle, small_volume_file, monkeypatch):
     """add_ngrad_noise: Gaussian noise on dn/dx, dn/dy in the Euler march (trilinear branch)."""
     monkeypatch.setenv("PHOTON_NOISE_SEED", "5")
