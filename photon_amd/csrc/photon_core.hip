@@ -441,6 +441,9 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 #ifndef PHOTON_MARCH_PERSISTENT
 #define PHOTON_MARCH_PERSISTENT 1
 #endif
+#ifndef PHOTON_QUEUE_TRIVIAL_CYCLES
+#define PHOTON_QUEUE_TRIVIAL_CYCLES 50000u    // a group that took less (~20 us of shader clock) was no real work
+#endif
 constexpr unsigned kQueueStride = 16;                           // u32 per queue counter: one 64-byte line each
 [[maybe_unused]] constexpr unsigned kGroupsPerChunk = PHOTON_XCD_CHUNK * 4;      // 64-ray groups per 8K-ray chunk
 
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
             unsigned k0 = 0;
             if (lane == 0) k0 = atomicAdd(&march_args()->queue[x * kQueueStride], batch);
             k0 = (unsigned)__builtin_amdgcn_readfirstlane((int)k0);
-            unsigned long long last_cycles = 0;
+            unsigned last_cycles = 0;                          // shader-clock ticks of the batch's last group (32 bits: ~2 s)
             for (unsigned i = 0; i < batch; i++) {
             const unsigned k = k0 + i;
             MarchArgsPtr a = march_args();
@@ -544,9 +547,12 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
             clock_stamp(clk1, real1);
             if (group_marched) { n_marched += group_marched; clk_sum += clk1 - clk0; real_sum += real1 - real0; }
 #if PHOTON_MARCH_PERSISTENT
-            last_cycles = clk1 - clk0;
+            last_cycles = (unsigned)(clk1 - clk0);
             }
-            batch = last_cycles < 50000ull ? (batch < 64u ? batch * 2u : 64u) : 1u;     // ~20 us of shader clock
+            // only a batch that was served in full and took no time argues for a larger one; the end of a queue does not
+            // (a wave that went on to the next XCD's leftovers with a doubled batch each time ended up holding 32-64 real
+            // groups -- a minute of work -- while the rest of the chip had left: measured, 59 -> 120 ms)
+            batch = (!served && last_cycles < PHOTON_QUEUE_TRIVIAL_CYCLES) ? (batch < 64u ? batch * 2u : 64u) : 1u;
 #else
             }
             }
