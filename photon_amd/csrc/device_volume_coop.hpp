@@ -46,7 +46,10 @@ namespace photon {
 #endif
 constexpr int kBrickPitch = PHOTON_BRICK_PITCH;                  // texels between consecutive rows of the brick
 constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels between consecutive z-slabs
-constexpr int kWaveLdsTexels = 64 + 4 * kBrickSlab;             // per wave: the 4x4x4 tile + the 8x8x4 brick (8x8x2 for trilinear)
+// per wave: the tile (64 texels reserved; trilinear uses 8) + the brick: 8x8x4 texels for the tricubic sampler, 8x8x2 for
+// the trilinear one -- 7 KiB against 4 KiB, i.e. at most 5 against 10 workgroups of four waves in a CU's 160 KiB
+template <int INTERP> constexpr int wave_lds_texels() { return 64 + (INTERP == 2 ? 4 : 2) * kBrickSlab; }
+constexpr int kWaveLdsTexels = wave_lds_texels<2>();
 
 // 64-tap sum (slab order) over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
 // is one broadcast ds_read_b128.  Plain (unpacked) f32 FMAs on purpose: on gfx950 v_pk_fma_f32 issues

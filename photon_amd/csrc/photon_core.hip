@@ -477,7 +477,7 @@ __device__ __forceinline__ MarchArgsPtr march_args() {
 
 template <int ALGO, int INTERP, bool SAVE, bool NOISE>
 __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(MarchArgs) {
-    __shared__ f4 tiles[PHOTON_MARCH_BLOCK / 64][kWaveLdsTexels];                     // per wave: 4x4x4 tile + 8x8x4 brick, rows padded (device_volume_coop.hpp)
+    __shared__ f4 tiles[PHOTON_MARCH_BLOCK / 64][wave_lds_texels<INTERP>()];           // per wave: tile + brick, rows padded (device_volume_coop.hpp)
     const unsigned lane = threadIdx.x & 63u;
     WaveCount mc{0u, 0u};                                       // wave-uniform totals (SGPRs), over all groups of this wave
     unsigned n_marched = 0;
