@@ -434,17 +434,14 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 // generations lasted about G + 0.9 lifetimes -- one GPU's eighth of C3, 3.8 generations, ran at 81 % occupancy).
 // Here the grid is just large enough to fill the chip ONCE and every wave takes 64-ray groups from a queue until the
 // launch is served: a wave that finishes a group loads the next one itself, no slot waits for the dispatcher.
-// One queue per XCD (workgroup i runs on XCD i % 8): a queue hands out the groups of every eighth 8K-ray chunk in
-// order, so rays that walk the same voxels still meet in one L2 (what xcd_remap did for the one-shot launch); a wave
-// whose own queue is empty serves the others' leftovers, so the launch ends without a straggling XCD.  Every wave
-// leaves as soon as all eight queues are past their ends.
+// 64 queues, eight per XCD (workgroup i runs on XCD i % 8), each handing out the groups of its 8K-ray chunks in order, so
+// rays that walk the same voxels still meet in one L2 (what xcd_remap did for the one-shot launch); the visiting order and
+// why 64 are at the loop.  Every wave leaves as soon as its fifteen queues are past their ends.
 #ifndef PHOTON_MARCH_PERSISTENT
 #define PHOTON_MARCH_PERSISTENT 1
 #endif
-#ifndef PHOTON_QUEUE_TRIVIAL_CYCLES
-#define PHOTON_QUEUE_TRIVIAL_CYCLES 50000u    // a group that took less (~20 us of shader clock) was no real work
-#endif
 constexpr unsigned kQueueStride = 16;                           // u32 per queue counter: one 64-byte line each
+constexpr unsigned kQueues = 64;                                // 8 XCDs x 8 sub-queues
 [[maybe_unused]] constexpr unsigned kGroupsPerChunk = PHOTON_XCD_CHUNK * 4;      // 64-ray groups per 8K-ray chunk
 
 // The march kernel's arguments, read from the kernel-argument segment WHERE THEY ARE USED (scalar loads through a pointer
@@ -483,25 +480,27 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
     unsigned n_marched = 0;
     unsigned long long clk_sum = 0, real_sum = 0;
 #if PHOTON_MARCH_PERSISTENT
-    const unsigned home = blockIdx.x & 7u;
-    // Groups per queue access: 1 while groups are real work (~1.8 ms each: the finest balance at the end of the launch),
-    // doubling up to 64 while they are trivial -- a launch whose rays all miss the volume (the reference's sample BOS case)
-    // would otherwise spend its time on ~1e6 returning atomics to eight addresses.
-    unsigned batch = 1;
-    for (unsigned q = 0; q < 8u; q++) {
-        const unsigned x = (home + q) & 7u;                     // own XCD's queue first, then the others' leftovers
-        bool served = false;
-        while (!served) {
-            unsigned k0 = 0;
-            if (lane == 0) k0 = atomicAdd(&march_args()->queue[x * kQueueStride], batch);
-            k0 = (unsigned)__builtin_amdgcn_readfirstlane((int)k0);
-            unsigned last_cycles = 0;                          // shader-clock ticks of the batch's last group (32 bits: ~2 s)
-            for (unsigned i = 0; i < batch; i++) {
-            const unsigned k = k0 + i;
+    // 64 queues: XCD x (workgroup i runs on XCD i % 8) owns the 8K-ray chunks c with c % 8 == x, dealt over its eight
+    // sub-queues by (c / 8) % 8.  One counter per queue, a cache line apart: with one queue per XCD a launch whose groups
+    // are no work (every ray misses the volume: the reference's sample BOS case, ~1e6 groups) spent its time on returning
+    // atomics to eight addresses (one-shot launch 7.6 ms, one queue per XCD 9.1, sixty-four queues 7.8).  A wave serves its
+    // home sub-queue, then the other seven of its XCD (between them the XCD's waves drain all eight: every group is
+    // taken), then the same sub-queue of the seven other XCDs (balance at the end of the launch).  Taking several groups
+    // per access instead was tried and dropped: wherever trivial and real groups mix (doomed lens samples of a PIV
+    // launch) a wave ends up holding dozens of real groups while the chip drains (C5 quarter 38.6 -> 92 ms).
+    const unsigned home_x = blockIdx.x & 7u, home_s = (blockIdx.x >> 3) & 7u;
+    for (unsigned step = 0; step < 15u; step++) {
+        const unsigned x = step < 8u ? home_x : ((home_x + step - 7u) & 7u);
+        const unsigned sub = step < 8u ? ((home_s + step) & 7u) : home_s;
+        while (true) {
+            {
+            unsigned k = 0;
+            if (lane == 0) k = atomicAdd(&march_args()->queue[(sub * 8u + x) * kQueueStride], 1u);
+            k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             MarchArgsPtr a = march_args();
             const unsigned n_rays = a->n_rays;
-            const unsigned group = ((k / kGroupsPerChunk) * 8u + x) * kGroupsPerChunk + k % kGroupsPerChunk;
-            if (group >= (n_rays + 63u) / 64u) { served = true; break; }      // groups grow with k: this queue is served
+            const unsigned group = (((k / kGroupsPerChunk) * 8u + sub) * 8u + x) * kGroupsPerChunk + k % kGroupsPerChunk;
+            if (group >= (n_rays + 63u) / 64u) break;           // groups grow with k: this queue is served
 #else
     {
         {
@@ -547,12 +546,7 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
             clock_stamp(clk1, real1);
             if (group_marched) { n_marched += group_marched; clk_sum += clk1 - clk0; real_sum += real1 - real0; }
 #if PHOTON_MARCH_PERSISTENT
-            last_cycles = (unsigned)(clk1 - clk0);
             }
-            // only a batch that was served in full and took no time argues for a larger one; the end of a queue does not
-            // (a wave that went on to the next XCD's leftovers with a doubled batch each time ended up holding 32-64 real
-            // groups -- a minute of work -- while the rest of the chip had left: measured, 59 -> 120 ms)
-            batch = (!served && last_cycles < PHOTON_QUEUE_TRIVIAL_CYCLES) ? (batch < 64u ? batch * 2u : 64u) : 1u;
 #else
             }
             }
@@ -817,7 +811,7 @@ struct photon_scene {
     RayStateDev ws{};                   // march -> sensor state, grown on demand
     size_t ws_rays = 0;
     unsigned long long *d_counters = nullptr;
-    unsigned *d_queue = nullptr;        // the march's work queues: one counter per XCD, a cache line apart
+    unsigned *d_queue = nullptr;        // the march's work queues: 64 counters (8 XCDs x 8 sub-queues), a cache line apart
     int num_cus = 256;                  // compute units of the scene's device (size of the persistent march grid)
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1487,7 +1481,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     e = hipMalloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
-    e = hipMalloc((void **)&s->d_queue, 8 * kQueueStride * sizeof(unsigned));
+    e = hipMalloc((void **)&s->d_queue, kQueues * kQueueStride * sizeof(unsigned));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     {
         int dev = 0, cus = 0;
@@ -1695,7 +1689,7 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         const unsigned fill_blocks = (unsigned)s->num_cus * 8u * (256 / PHOTON_MARCH_BLOCK);
         const dim3 mblock(PHOTON_MARCH_BLOCK), mgrid(PHOTON_MARCH_PERSISTENT ? std::min(all_blocks, fill_blocks) : all_blocks);
         if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2))
-            PH_CHECK(hipMemsetAsync(s->d_queue, 0, 8 * kQueueStride * sizeof(unsigned), stream));
+            PH_CHECK(hipMemsetAsync(s->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned), stream));
         if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
         const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue};
 #define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), mgrid, mblock, 0, stream, margs)
