@@ -261,6 +261,11 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
  * start_ray_tracing reads it from PHOTON_ELEMENT_TRAIN=reference|sequential. */
 int photon_scene_set_element_train(photon_scene_t *scene, int mode);
 
+/* The partition of a march launch over its 64 work queues (host restatement of the kernel's own function, for tests):
+ * index of the k-th 64-ray group handed out by sub-queue `sub` (0..7) of XCD `xcd` (0..7).  A launch of G groups is
+ * served when every queue has handed out all its groups below G; each group belongs to exactly one queue. */
+unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub);
+
 /* A scene that holds only a SLICE of a job's source list (one rank of a multi-GPU job uploads just its shard): the
  * index, in the job's list, of this scene's first source.  Only the noise hooks read it -- their generator is keyed by the
  * ray's place in the whole job, so a sharded render draws the numbers the unsharded one draws.  Default 0. */

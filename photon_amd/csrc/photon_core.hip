@@ -443,6 +443,11 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 constexpr unsigned kQueueStride = 16;                           // u32 per queue counter: one 64-byte line each
 constexpr unsigned kQueues = 64;                                // 8 XCDs x 8 sub-queues
 [[maybe_unused]] constexpr unsigned kGroupsPerChunk = PHOTON_XCD_CHUNK * 4;      // 64-ray groups per 8K-ray chunk
+// The k-th group handed out by sub-queue `sub` of XCD `xcd`: chunk ((k / C) * 8 + sub) * 8 + xcd, group k % C of it.  Grows
+// with k, so the first k whose group lies past the launch ends the queue; every group belongs to exactly one (xcd, sub).
+__host__ __device__ inline unsigned march_queue_group(unsigned k, unsigned xcd, unsigned sub) {
+    return (((k / kGroupsPerChunk) * 8u + sub) * 8u + xcd) * kGroupsPerChunk + k % kGroupsPerChunk;
+}
 
 // The march kernel's arguments, read from the kernel-argument segment WHERE THEY ARE USED (scalar loads through a pointer
 // the optimiser cannot see through) instead of being held in SGPRs from the prologue on: the persistent loop needs them
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
             k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             MarchArgsPtr a = march_args();
             const unsigned n_rays = a->n_rays;
-            const unsigned group = (((k / kGroupsPerChunk) * 8u + sub) * 8u + x) * kGroupsPerChunk + k % kGroupsPerChunk;
+            const unsigned group = march_queue_group(k, x, sub);
             if (group >= (n_rays + 63u) / 64u) break;           // groups grow with k: this queue is served
 #else
     {
@@ -1503,6 +1508,8 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
                                 (unsigned long long)seed};
     return 0;
 }
+
+unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub) { return march_queue_group(k, xcd & 7u, sub & 7u); }
 
 int photon_scene_set_source_base(photon_scene_t *s, int64_t first_source) {
     if (!s || first_source < 0) return 1;

@@ -93,3 +93,31 @@ def test_tiff_and_raw_writers_round_trip(tmp_path):
         assert f.read(4) == b"II*\x00"
     write_tiff_u16(str(tmp_path / "odd.tif"), np.arange(15, dtype=np.uint16).reshape(3, 5))
     assert np.array_equal(read_tiff_u16(str(tmp_path / "odd.tif")), np.arange(15).reshape(3, 5))
+
+
+def test_march_work_queues_partition_every_launch():
+    """The 64 work queues of the persistent march (8 XCDs x 8 sub-queues): for any number of 64-ray groups every group
+    below it is handed out by exactly one queue, each queue hands its groups out in increasing order (so the first one
+    past the end ends the queue), and consecutive groups of an 8K-ray chunk come from ONE queue (L2 locality).  Host
+    restatement of the kernel's own function, through the C-ABI; no GPU needed."""
+    import ctypes
+    from photon_amd import build
+    lib = ctypes.CDLL(build.build_library(verbose=False))
+    f = lib.photon_march_queue_group
+    f.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    f.restype = ctypes.c_uint
+    for n_groups in (1, 127, 128, 129, 1023, 8 * 128 + 5, 64 * 128, 64 * 128 + 1, 19532):
+        seen = np.zeros(n_groups, np.int32)
+        for x in range(8):
+            for sub in range(8):
+                last, k = -1, 0
+                while True:
+                    g = f(k, x, sub)
+                    assert g > last                    # monotonic: a queue ends at its first group past the launch
+                    last = g
+                    if g >= n_groups:
+                        break
+                    seen[g] += 1
+                    assert (g // 128) % 8 == x and (g // 128 // 8) % 8 == sub
+                    k += 1
+        assert (seen == 1).all(), n_groups

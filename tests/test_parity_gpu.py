@@ -413,6 +413,39 @@ def test_position_noise_hook(photon, oracle, monkeypatch):
     oracle.set_noise_seed(0)
 
 
+def test_statistics_window_sums_the_traces(photon, small_volume_file):
+    """photon_scene_stats_begin / _end: counters and event times summed over the traces of a window (no host sync inside
+    it) equal what the same traces report one by one; the march's own clock stamps give a plausible shader clock; per-call
+    stats inside an open window are refused."""
+    import torch
+    from photon_amd.library import PhotonError
+    call = scenes.bos_scene(n_dots=6, points_per_dot=20, rays_per_source=100, density_grad_filename=small_volume_file)
+    H, W = call.image_shape
+    scene = photon.scene_create(call)
+    vol = photon.volume_load_nrrd(small_volume_file, 2)
+    img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    one = scene.trace(img.data_ptr(), vol, 2, want_stats=True)
+    assert one.traces == 1 and one.rays_marched == call.num_rays and one.march_ms > 0
+    single = img.cpu().numpy().copy()
+    img.zero_()
+    scene.stats_begin()
+    for _ in range(3):
+        scene.trace(img.data_ptr(), vol, 2)
+    with pytest.raises(PhotonError):
+        scene.trace(img.data_ptr(), vol, 2, want_stats=True)
+    st = scene.stats_end()
+    assert st.traces == 3 and st.rays_launched == 3 * call.num_rays
+    for f in ("rays_on_sensor", "rk_iterations", "volume_samples", "sensor_taps", "rays_marched"):
+        assert getattr(st, f) == 3 * getattr(one, f), f
+    assert 0 < st.march_ms <= st.total_ms
+    assert 1000.0 < st.shader_clock_mhz < 3000.0 and st.march_wave_ms > 0
+    assert rel_l2(img.cpu().numpy(), 3 * single) <= 1e-6
+    with pytest.raises(PhotonError):
+        scene.stats_end()                                   # no window open any more
+    scene.free()
+    vol.free()
+
+
 def test_scene_slices_keep_job_wide_noise_ids(photon, small_volume_file):
     """photon_scene_set_source_base: a scene that holds only a slice of the job's sources (one rank of a sharded job)
     draws the noise the whole-job scene draws for those rays -- position noise in the sensor stage, gradient noise in
