@@ -107,6 +107,9 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #ifndef PHOTON_DPP_SLAB
 #define PHOTON_DPP_SLAB 1
 #endif
+#ifndef PHOTON_DPP_ROWS
+#define PHOTON_DPP_ROWS 4           // rows of z-slab 0 (four taps each) served from registers; the rest of the slab comes from LDS
+#endif
 // The coherent tile's 64-tap sum with z-slab 0 served from REGISTERS instead of LDS (PHOTON_DPP_SLAB=1): `reg` holds, in
 // every 16-lane row of the wave, the 16 texels of slab 0 (lane l: texel l & 15), and its 16 taps are v_fmac_f32_dpp with
 // row_newbcast:k -- every lane multiplies ITS weight with lane k's texel.  16 of the sample's 64 broadcast ds_read_b128
@@ -119,9 +122,90 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 // traffic inside inline asm, finds nothing outstanding after it.  The DPP operand registers (reg) are not written
 // inside the block; the s_nop covers the EXEC-write / VALU-write -> DPP hazards of whatever precedes it (the compiler's
 // hazard recogniser does not look into inline asm).
+#define PH_DPP_ROW0 \
+    "v_mul_f32_dpp %0, %8, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mul_f32_dpp %1, %9, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mul_f32_dpp %2, %10, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mul_f32_dpp %3, %11, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+#define PH_DPP_ROW1 \
+    "v_fmac_f32_dpp %0, %8, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+#define PH_DPP_ROW2 \
+    "v_fmac_f32_dpp %0, %8, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+#define PH_DPP_ROW3 \
+    "v_fmac_f32_dpp %0, %8, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %0, %8, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %1, %9, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %2, %10, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %3, %11, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+#define PH_STR2(x) #x
+#define PH_STR(x) PH_STR2(x)
+#if PHOTON_DPP_ROWS == 1
+#define PH_DPP_ROWS_TEXT PH_DPP_ROW0
+#elif PHOTON_DPP_ROWS == 2
+#define PH_DPP_ROWS_TEXT PH_DPP_ROW0 PH_DPP_ROW1
+#elif PHOTON_DPP_ROWS == 3
+#define PH_DPP_ROWS_TEXT PH_DPP_ROW0 PH_DPP_ROW1 PH_DPP_ROW2
+#else
+#define PH_DPP_ROWS_TEXT PH_DPP_ROW0 PH_DPP_ROW1 PH_DPP_ROW2 PH_DPP_ROW3
+#endif
 __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const float (&wx)[4], const float (&wy)[4],
                                                 const float (&wz)[4]) {
     typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int R = PHOTON_DPP_ROWS;                              // rows (of four taps) of z-slab 0 served from registers
+    static_assert(R >= 1 && R <= 4, "PHOTON_DPP_ROWS");
     float wxy[4][4];
 #pragma unroll
     for (int b = 0; b < 4; b++)
@@ -129,77 +213,14 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
         for (int a = 0; a < 4; a++) wxy[b][a] = wx[a] * wy[b];
     v4f t0, t1, t2, t3;
     f4 s;
-    const unsigned lds = (unsigned)(size_t)blk;                     // LDS byte address of the tile (low half of the flat address)
+    const unsigned lds = (unsigned)(size_t)blk + 64u * R;           // LDS byte address of the first row read from the tile
     asm volatile(
-            "ds_read_b128 %4, %28 offset:256\n\t"
-            "ds_read_b128 %5, %28 offset:272\n\t"
-            "ds_read_b128 %6, %28 offset:288\n\t"
-            "ds_read_b128 %7, %28 offset:304\n\t"
+            "ds_read_b128 %4, %28\n\t"
+            "ds_read_b128 %5, %28 offset:16\n\t"
+            "ds_read_b128 %6, %28 offset:32\n\t"
+            "ds_read_b128 %7, %28 offset:48\n\t"
             "s_nop 4\n\t"
-            "v_mul_f32_dpp %0, %8, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mul_f32_dpp %1, %9, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mul_f32_dpp %2, %10, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mul_f32_dpp %3, %11, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %22 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %24 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %25 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %26 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %8, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %9, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %10, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %11, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            PH_DPP_ROWS_TEXT
             "s_waitcnt lgkmcnt(0)"
             : "=&v"(s.x), "=&v"(s.y), "=&v"(s.z), "=&v"(s.w), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
             : "v"(reg.x), "v"(reg.y), "v"(reg.z), "v"(reg.w), "v"(wxy[0][0]), "v"(wxy[0][1]), "v"(wxy[0][2]), "v"(wxy[0][3]),
@@ -207,10 +228,11 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
               "v"(wxy[2][3]), "v"(wxy[3][0]), "v"(wxy[3][1]), "v"(wxy[3][2]), "v"(wxy[3][3]), "v"(lds)
             : "memory");
     f4 t[4] = {f4{t0.x, t0.y, t0.z, t0.w}, f4{t1.x, t1.y, t1.z, t1.w}, f4{t2.x, t2.y, t2.z, t2.w}, f4{t3.x, t3.y, t3.z, t3.w}};
-    f4 acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
+    f4 acc = f4{0, 0, 0, 0};
+    if (R == 4) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};     // slab 0 complete (else: at r == 3 below)
     float w0 = wxy[0][0];
 #pragma unroll
-    for (int r = 4; r < 16; r++) {                                  // slabs 1..3 from the LDS tile, as in cubic_taps_lds
+    for (int r = R; r < 16; r++) {                                  // the rest of the tile from LDS, as in cubic_taps_lds
         const int b = r & 3, c = r >> 2;
 #pragma unroll
         for (int a = 0; a < 4; a++) {
@@ -223,7 +245,8 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
             asm volatile("" : "+v"(w0) : : "memory");
         }
         if (b == 3) {
-            acc = f4{fmaf(wz[c], s.x, acc.x), fmaf(wz[c], s.y, acc.y), fmaf(wz[c], s.z, acc.z), fmaf(wz[c], s.w, acc.w)};
+            if (c == 0) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
+            else acc = f4{fmaf(wz[c], s.x, acc.x), fmaf(wz[c], s.y, acc.y), fmaf(wz[c], s.z, acc.z), fmaf(wz[c], s.w, acc.w)};
             asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
         }
     }
