@@ -127,12 +127,10 @@ __device__ __forceinline__ unsigned long long *counter_slot(unsigned long long *
 #define PHOTON_XCD_CHUNK 32
 #endif
 #ifndef PHOTON_MARCH_BLOCK
-#define PHOTON_MARCH_BLOCK_FOR_REMAP 256
-#else
-#define PHOTON_MARCH_BLOCK_FOR_REMAP PHOTON_MARCH_BLOCK
+#define PHOTON_MARCH_BLOCK 256          // threads per workgroup of the march (a multiple of 64)
 #endif
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
-    constexpr unsigned B = PHOTON_XCD_CHUNK * (256 / PHOTON_MARCH_BLOCK_FOR_REMAP);
+    constexpr unsigned B = PHOTON_XCD_CHUNK * (256 / PHOTON_MARCH_BLOCK);
     const unsigned full = nb / (8u * B) * (8u * B);            // blocks that form complete rounds of 8 chunks
     if (bid >= full) return bid;
     const unsigned xcd = bid & 7u, q = bid >> 3;                // q-th block this XCD receives
@@ -424,9 +422,6 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk), "=s"(real) : : "memory");
 }
 
-#ifndef PHOTON_MARCH_BLOCK
-#define PHOTON_MARCH_BLOCK 256          // threads per workgroup of the march (a multiple of 64)
-#endif
 // PERSISTENT WAVES (round 3).  Every ray of a BOS launch marches for the same ~1.8 ms, so the waves of a conventional
 // launch finish generation by generation, and each time the dispatcher has a whole chip's worth of workgroups to start at
 // once: measured on C3, the resident-wave slots stood empty 7.5 % of the kernel's time (156 250 waves x 1.76 ms mean
@@ -477,13 +472,60 @@ __device__ __forceinline__ MarchArgsPtr march_args() {
     return p;
 }
 
+// What a march wave accumulates over the groups it serves (wave-uniform: SGPRs) and adds to the counters once, at its end.
+struct WaveTotals {
+    WaveCount mc{0u, 0u};
+    unsigned n_marched = 0;                                     // rays that entered the march (not skipped as doomed)
+    unsigned long long clk_sum = 0, real_sum = 0;               // shader-clock / 100 MHz ticks spent in groups
+};
+
+// One 64-ray group: load the state, march, store it back.  Must be called by all 64 lanes of the wave.
+template <int ALGO, int INTERP, bool SAVE, bool NOISE>
+__device__ __forceinline__ void march_group(unsigned group, unsigned n_rays, f4 *tile, WaveTotals &tot) {
+    unsigned long long clk0, real0, clk1, real1;
+    clock_stamp(clk0, real0);
+    const unsigned r = group * 64u + (threadIdx.x & 63u);
+    const bool has_ray = r < n_rays;
+    f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
+    bool marching = has_ray;
+    MarchArgsPtr a = march_args();
+    {
+        const RayStateDev st = load_arg(&a->st);
+        if (has_ray) {
+            p = mk3(st.px[r], st.py[r], st.pz[r]);
+            d = mk3(st.dx[r], st.dy[r], st.dz[r]);
+            marching = !isnan3(p);                              // rays marked dead by raygen_kernel stay out of the march
+        }
+    }
+    const unsigned group_marched = (unsigned)__popcll(ballot(marching));
+    const VolumeDev vol = load_arg(&a->vol);
+    const f4 *tex = a->tex;
+    GradNoise gn{0, 0.f, 0ull, 0ull};
+    if (NOISE) { const NoiseDev nz = load_arg(&a->noise); gn = GradNoise{nz.add_ngrad, nz.ngrad_std, nz.seed, a->ray_base + r}; }
+    InterDump idump{nullptr, nullptr, 0, 0, 0u};
+    if (SAVE) idump = load_arg(&a->idump);
+    idump.ray = r;                                              // chunk-global ray id, like the final dumps
+    if (INTERP == 1 && vol.weight_scale > 0.f)                  // kernel-uniform: the texture unit's 8-bit weights (the default) / exact f32
+        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tile, tot.mc, gn, idump);   // all 64 lanes
+    else
+        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, false, WaveCount>(marching, p, d, vol, tex, tile, tot.mc, gn, idump);
+    {
+        const RayStateDev st = load_arg(&march_args()->st);     // loaded again: not carried through the march in SGPRs
+        if (marching) {
+            st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
+            st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+        }
+    }
+    clock_stamp(clk1, real1);
+    if (group_marched) { tot.n_marched += group_marched; tot.clk_sum += clk1 - clk0; tot.real_sum += real1 - real0; }
+}
+
 template <int ALGO, int INTERP, bool SAVE, bool NOISE>
 __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(MarchArgs) {
     __shared__ f4 tiles[PHOTON_MARCH_BLOCK / 64][wave_lds_texels<INTERP>()];           // per wave: tile + brick, rows padded (device_volume_coop.hpp)
+    f4 *const tile = tiles[threadIdx.x >> 6];
     const unsigned lane = threadIdx.x & 63u;
-    WaveCount mc{0u, 0u};                                       // wave-uniform totals (SGPRs), over all groups of this wave
-    unsigned n_marched = 0;
-    unsigned long long clk_sum = 0, real_sum = 0;
+    WaveTotals tot;
 #if PHOTON_MARCH_PERSISTENT
     // 64 queues: XCD x (workgroup i runs on XCD i % 8) owns the 8K-ray chunks c with c % 8 == x, dealt over its eight
     // sub-queues by (c / 8) % 8.  One counter per queue, a cache line apart: with one queue per XCD a launch whose groups
@@ -498,74 +540,30 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
         const unsigned x = step < 8u ? home_x : ((home_x + step - 7u) & 7u);
         const unsigned sub = step < 8u ? ((home_s + step) & 7u) : home_s;
         while (true) {
-            {
             unsigned k = 0;
             if (lane == 0) k = atomicAdd(&march_args()->queue[(sub * 8u + x) * kQueueStride], 1u);
             k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-            MarchArgsPtr a = march_args();
-            const unsigned n_rays = a->n_rays;
+            const unsigned n_rays = march_args()->n_rays;
             const unsigned group = march_queue_group(k, x, sub);
             if (group >= (n_rays + 63u) / 64u) break;           // groups grow with k: this queue is served
-#else
-    {
-        {
-            {
-            MarchArgsPtr a = march_args();
-            const unsigned n_rays = a->n_rays;
-            const unsigned group = xcd_remap(blockIdx.x, gridDim.x) * (PHOTON_MARCH_BLOCK / 64) + (threadIdx.x >> 6);
-            if (group < (n_rays + 63u) / 64u) {
-#endif
-            unsigned long long clk0, real0, clk1, real1;
-            clock_stamp(clk0, real0);
-            const unsigned r = group * 64u + lane;
-            const bool has_ray = r < n_rays;
-            f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
-            bool marching = has_ray;
-            {
-                const RayStateDev st = load_arg(&a->st);
-                if (has_ray) {
-                    p = mk3(st.px[r], st.py[r], st.pz[r]);
-                    d = mk3(st.dx[r], st.dy[r], st.dz[r]);
-                    marching = !isnan3(p);                      // rays marked dead by raygen_kernel stay out of the march
-                }
-            }
-            const unsigned group_marched = (unsigned)__popcll(ballot(marching));   // rays that enter the march (not skipped as doomed)
-            const VolumeDev vol = load_arg(&a->vol);
-            const f4 *tex = a->tex;
-            GradNoise gn{0, 0.f, 0ull, 0ull};
-            if (NOISE) { const NoiseDev nz = load_arg(&a->noise); gn = GradNoise{nz.add_ngrad, nz.ngrad_std, nz.seed, a->ray_base + r}; }
-            InterDump idump{nullptr, nullptr, 0, 0, 0u};
-            if (SAVE) idump = load_arg(&a->idump);
-            idump.ray = r;                                      // chunk-global ray id, like the final dumps
-            if (INTERP == 1 && vol.weight_scale > 0.f)          // kernel-uniform: the texture unit's 8-bit weights (the default) / exact f32
-                trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);   // all 64 lanes
-            else
-                trace_volume_coop<ALGO, INTERP, SAVE, NOISE, false, WaveCount>(marching, p, d, vol, tex, tiles[threadIdx.x >> 6], mc, gn, idump);
-            {
-                const RayStateDev st = load_arg(&march_args()->st);        // loaded again: not carried through the march in SGPRs
-                if (marching) {
-                    st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
-                    st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
-                }
-            }
-            clock_stamp(clk1, real1);
-            if (group_marched) { n_marched += group_marched; clk_sum += clk1 - clk0; real_sum += real1 - real0; }
-#if PHOTON_MARCH_PERSISTENT
-            }
-#else
-            }
-            }
-#endif
+            march_group<ALGO, INTERP, SAVE, NOISE>(group, n_rays, tile, tot);
         }
     }
+#else
+    {                                                           // one-shot grid (A/B builds): one group per wave
+        const unsigned n_rays = march_args()->n_rays;
+        const unsigned group = xcd_remap(blockIdx.x, gridDim.x) * (PHOTON_MARCH_BLOCK / 64) + (threadIdx.x >> 6);
+        if (group < (n_rays + 63u) / 64u) march_group<ALGO, INTERP, SAVE, NOISE>(group, n_rays, tile, tot);
+    }
+#endif
     if (lane == 0) {
         unsigned long long *slot = counter_slot(march_args()->counters);
-        if (mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)mc.iterations);
-        if (mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)mc.samples);
-        if (n_marched) {
-            atomicAdd(&slot[CNT_MARCHED], (unsigned long long)n_marched);
-            atomicAdd(&slot[CNT_CLK], clk_sum);
-            atomicAdd(&slot[CNT_REAL], real_sum);
+        if (tot.mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)tot.mc.iterations);
+        if (tot.mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)tot.mc.samples);
+        if (tot.n_marched) {
+            atomicAdd(&slot[CNT_MARCHED], (unsigned long long)tot.n_marched);
+            atomicAdd(&slot[CNT_CLK], tot.clk_sum);
+            atomicAdd(&slot[CNT_REAL], tot.real_sum);
         }
     }
 }
