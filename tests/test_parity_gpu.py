@@ -143,6 +143,75 @@ def test_march_bit_exact(vol_pair, interp, algorithm):
     assert_bit_equal(gd, od, "marched directions")
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_march_bit_exact_on_adversarial_cases(photon, oracle, seed):
+    """Fuzz of the wave-cooperative march against the oracle, bit for bit, on what the hot path meets least often: tiny
+    and lopsided grids (down to 4 texels on an axis), a CONSTANT density (every blend sits exactly on data_min: the
+    linear branch's below-minimum repair, .h:1056-1065, decides on rounding), rays from every side -- grazing faces and
+    edges, axis-parallel (zero direction components: infinities in the slab test), starting on a face, inside, far away,
+    pointing away -- packed so that waves are partly coherent, partly not (tile, brick and gather paths in one launch),
+    Euler and RK4, both samplers, exact and 8-bit trilinear weights."""
+    rng = np.random.default_rng(1000 + seed)
+    dims = [(4, 5, 33), (17, 4, 9), (12, 12, 12), (40, 7, 21), (9, 31, 6), (24, 20, 28)][seed]          # nz, ny, nx
+    z, y, x = np.meshgrid(*(np.linspace(-1, 1, k) for k in dims), indexing="ij")
+    if seed == 2:
+        rho = np.full(dims, 1.225, np.float32)                                         # constant: n - 1 == data_min everywhere
+    else:
+        rho = (1.2 + 0.4 * np.exp(-(x ** 2 + 2 * y ** 2 + 0.5 * z ** 2) * 2) + 0.05 * rng.standard_normal(dims)).astype(np.float32)
+    spacing = tuple(float(v) for v in rng.uniform(80.0, 400.0, 3))
+    origin = (-1000.0, 500.0, 750e3 + 2000.0)
+    n = 4096
+    for interp in (1, 2):
+        g, o = photon.volume_from_density(rho, spacing, origin, interp), oracle.volume_from_density(rho, spacing, origin, interp)
+        i = g.info()
+        lo, hi = np.array(i.min_bound, np.float64), np.array(i.max_bound, np.float64)
+        ext = hi - lo
+        centre = 0.5 * (lo + hi)
+        # starts on a sphere around the box, aimed at random points of it; then the special families
+        u = rng.standard_normal((n, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        pos = centre + u * 1.5 * np.linalg.norm(ext)
+        target = lo + rng.uniform(-0.05, 1.05, (n, 3)) * ext
+        d = target - pos
+        pos[:400] = lo + rng.uniform(0, 1, (400, 3)) * ext                              # inside starts
+        d[:400] = rng.standard_normal((400, 3))
+        k = np.arange(400, 800)                                                        # axis-parallel, from outside
+        axis = rng.integers(0, 3, k.size)
+        d[k] = 0.0
+        d[k, axis] = np.where(pos[k, axis] > centre[axis], -1.0, 1.0)
+        pos[k] = lo + rng.uniform(0.01, 0.99, (k.size, 3)) * ext
+        pos[k, axis] = np.where(d[k, axis] < 0, hi[axis] + 300.0, lo[axis] - 300.0)
+        k = np.arange(800, 1000)                                                       # start exactly on the max-z face, heading in
+        pos[k] = lo + rng.uniform(0.05, 0.95, (k.size, 3)) * ext
+        pos[k, 2] = np.float32(hi[2])
+        d[k] = np.stack([rng.normal(0, 0.2, k.size), rng.normal(0, 0.2, k.size), -np.ones(k.size)], 1)
+        d[1000:1100] *= -1.0                                                           # pointing away: a miss
+        pos[1100:1164] = pos[1100] + rng.uniform(-1e-3, 1e-3, (64, 3))                 # one fully coherent wave's worth
+        d[1100:1164] = d[1100]
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        order = rng.permutation(n)
+        order[:1164] = np.arange(1164)                                                 # families contiguous, the rest shuffled
+        pos, d = pos[order], d[order]
+        for bits in ((8, 0) if interp == 1 else (8,)):
+            if interp == 1:
+                g.set_weight_bits(bits)
+                o2 = oracle.volume_from_density(rho, spacing, origin, 1, tex_frac_bits=bits)
+            else:
+                o2 = o
+            for algorithm in (1, 2):
+                gp, gd, gs = g.trace_rays(pos, d, algorithm)
+                op, od, os_ = o2.trace_rays(pos, d, algorithm)
+                what = f"seed {seed} interp {interp} bits {bits} algorithm {algorithm}"
+                assert np.array_equal(gs, os_), f"{what}: iteration counts differ at {np.flatnonzero(gs != os_)[:5]}"
+                assert_bit_equal(gp, op, what + " positions")
+                assert_bit_equal(gd, od, what + " directions")
+            if o2 is not o:
+                o2.free()
+        assert gs.max() > 2
+        g.free()
+        o.free()
+
+
 @pytest.mark.parametrize("algorithm", [3, 4, 0, 7])
 def test_other_integrators_bit_exact(vol_pair, algorithm):
     """ray_tracing_algorithm 3 (rk45, .h:304-718), 4 (adams_bashforth, .h:1293-1453) and the reference's
