@@ -186,6 +186,52 @@ def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source
             "other_configs": legs}
 
 
+class PowerSampler:
+    """Board power of the device under the timed loop, from the kernel driver's hwmon node (power1_input, microwatts;
+    power1_cap = the limit the firmware enforces), sampled by a thread while the main thread is inside the library (ctypes
+    releases the GIL).  The march holds its clock below the 2.4 GHz maximum; this says whether the power limit is why."""
+
+    def __init__(self, pci_bus_id: str, period_s: float = 0.004):
+        import threading
+        self.samples, self.cap_w, self.path = [], None, None
+        self._stop = threading.Event()
+        self._period = period_s
+        for hw in glob.glob(f"/sys/bus/pci/devices/{pci_bus_id}/hwmon/hwmon*") if pci_bus_id else []:
+            if os.path.exists(os.path.join(hw, "power1_input")):
+                self.path = os.path.join(hw, "power1_input")
+                try:
+                    with open(os.path.join(hw, "power1_cap")) as f:
+                        self.cap_w = int(f.read()) * 1e-6
+                except Exception:
+                    pass
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.path else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                with open(self.path) as f:
+                    self.samples.append(int(f.read()) * 1e-6)
+            except Exception:
+                pass
+            self._stop.wait(self._period)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=1.0)
+        if not self.samples:
+            return None
+        xs = sorted(self.samples)
+        return {"mean_w": round(sum(xs) / len(xs), 1), "median_w": round(xs[len(xs) // 2], 1), "max_w": round(xs[-1], 1),
+                "cap_w": self.cap_w, "samples": len(xs), "source": self.path,
+                "what": "board power over the timed loop (hwmon power1_input, an average the firmware publishes)"}
+
+
 def measure_hbm_traffic(args, kernel_tag: str):
     """HBM bytes per launch of the march kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE each in its own run, no tracing alongside) over a short child run of this same bench, corrected
@@ -362,6 +408,8 @@ def main():
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
+    power = PowerSampler(lib.pci_bus_id() if rank == 0 else "")
+    power.start()
     t0 = time.perf_counter()
     march_ms, iters, samples, taps, on_sensor, marched, clock_mhz, wave_ms = 0.0, 0, 0, 0, 0, 0, 0.0, 0.0
     for _ in range(args.steps):
@@ -375,6 +423,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    power_w = power.stop()
     if windowed:                        # sums over the K timed steps, read AFTER the timed region
         st = scene.stats_end(stream)
         k = max(int(st.traces), 1)
@@ -420,6 +469,7 @@ def main():
                 "clock_mhz": round(clock_mhz, 1) if clock_mhz > 0 else None,
                 "wave_lifetime_ms": round(wave_ms, 4) if wave_ms > 0 else None,
                 "wave_generations": round(rays_rank / 64 / (256 * 4 * 5), 2),
+                "board_power": power_w,
                 "peak_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
                 "frac_at_clock": round(achieved / peak_at_clock, 4) if peak_at_clock else None,
                 "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),

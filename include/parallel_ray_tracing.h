@@ -201,6 +201,10 @@ typedef struct photon_trace_stats_t {
 /* Select the GPU this thread's subsequent photon_* calls use (hipSetDevice). */
 int photon_set_device(int device);
 
+/* PCI bus id ("0000:c1:00.0") of the calling thread's current device: names its sysfs node
+ * (/sys/bus/pci/devices/<id>/hwmon/...: board power, cap) for measurement scripts. */
+int photon_device_pci_bus_id(char *buf, int len);
+
 /* glibc-compatible lens-sample table, factored out of parallel_ray_tracing.cu:3216-3243
  * (srand(10); r1[k]=rand()/RAND_MAX; r2[k]=rand()/RAND_MAX, interleaved).  Host arrays. */
 int photon_rand_table(int n, float *r1, float *r2);

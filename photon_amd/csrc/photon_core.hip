@@ -940,6 +940,14 @@ int photon_set_device(int device) {
     return 0;
 }
 
+int photon_device_pci_bus_id(char *buf, int len) {
+    if (!buf || len < 16) return 1;
+    int dev = 0;
+    PH_CHECK(hipGetDevice(&dev));
+    PH_CHECK(hipDeviceGetPCIBusId(buf, len, dev));
+    return 0;
+}
+
 int photon_rand_table(int n, float *r1, float *r2) {
     if (n < 0) return 1;
     std::vector<int> seq;

@@ -18,7 +18,7 @@ from .ray_tracing import (RayTracingCall, bind_start_ray_tracing, camera_design_
 
 # every symbol include/parallel_ray_tracing.h declares
 DECLARED_SYMBOLS = (
-    "start_ray_tracing", "photon_set_device", "photon_rand_table", "photon_volume_load_nrrd",
+    "start_ray_tracing", "photon_set_device", "photon_device_pci_bus_id", "photon_rand_table", "photon_volume_load_nrrd",
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
     "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_march_queue_group", "photon_trace",
     "photon_scene_stats_begin", "photon_scene_stats_end", "photon_trace_volume_rays", "photon_version",
@@ -192,6 +192,14 @@ class PhotonLibrary:
             image = call.new_image()
         call.invoke(self.start_ray_tracing, image)
         return image
+
+    def pci_bus_id(self) -> str:
+        """PCI bus id of the current device, lower case as sysfs spells it ('0000:c1:00.0'); '' if unavailable."""
+        if not hasattr(self.lib, "photon_device_pci_bus_id"):
+            return ""
+        buf = ctypes.create_string_buffer(64)
+        self.lib.photon_device_pci_bus_id.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        return buf.value.decode().lower() if self.lib.photon_device_pci_bus_id(buf, 64) == 0 else ""
 
     def measure_copy_gbs(self, nbytes: int = 1 << 30, reps: int = 5) -> float:
         """Device-to-device float4 copy rate (read + write), GB/s."""
