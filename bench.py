@@ -479,9 +479,12 @@ def main():
                              "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "flops_per_sample": flops_per_sample},
                 "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "compulsory_bytes": compulsory, "traffic": None,
                         "traffic_gbs": None, "frac": None},
-                "note": "bound = the pipe the kernel actually moves SURVEY 8d's algorithmic bytes through: LDS broadcast "
-                        "reads (guide: ~150 TB/s aggregate), co-limited by the f32 VALU chain (valu_f32); HBM only sees the "
-                        "ray state and one pass over the touched texels (hbm.traffic, measured by rocprofv3 --pmc in this run)"}
+                "note": "bound = the pipe built to deliver SURVEY 8d's algorithmic bytes (texel bytes consumed by the multiply-add "
+                        "chain): LDS broadcast reads (guide: ~150 TB/s aggregate at 2.4 GHz; peak_at_clock = 256 B/clk/CU x 256 CUs x the "
+                        "clock the march measured for itself).  Since round 3, 16 of a tricubic sample's 64 texel reads are register "
+                        "broadcasts (DPP), so the LDS array is ~72 % busy while the delivered texel rate is frac_at_clock of the LDS roof; "
+                        "the f32 VALU (valu_f32) is the co-limiter and the board's power cap (board_power) the limit behind both.  HBM only "
+                        "sees the ray state and the touched texels (hbm.traffic, measured by rocprofv3 --pmc in this run)"}
 
     out = None
     if rank == 0:
