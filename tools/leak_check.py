@@ -25,4 +25,14 @@ sc = lib.scene_create(call); vol = lib.volume_load_nrrd(path, 2)
 img = torch.zeros(1024 * 1024, device="cuda")
 a = used()
 for _ in range(300): sc.trace(img.data_ptr(), vol, 2, want_stats=True)
-print(f"photon_trace x300: {a:.1f} -> {used():.1f} MiB")
+b = used()
+for _ in range(300): sc.trace(img.data_ptr(), vol, 2, want_stats=True)
+c = used()
+sc.stats_begin()
+for _ in range(300): sc.trace(img.data_ptr(), vol, 2)
+sc.stats_end()
+d = used()
+sc.stats_begin()
+for _ in range(300): sc.trace(img.data_ptr(), vol, 2)
+sc.stats_end()
+print(f"photon_trace x300 with stats: {a:.1f} -> {b:.1f} -> (300 more) {c:.1f} MiB; in a statistics window: -> {d:.1f} -> (300 more) {used():.1f} MiB")
