@@ -190,8 +190,6 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     "v_fmac_f32_dpp %1, %9, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" \
     "v_fmac_f32_dpp %2, %10, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" \
     "v_fmac_f32_dpp %3, %11, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-#define PH_STR2(x) #x
-#define PH_STR(x) PH_STR2(x)
 #if PHOTON_DPP_ROWS == 1
 #define PH_DPP_ROWS_TEXT PH_DPP_ROW0
 #elif PHOTON_DPP_ROWS == 2

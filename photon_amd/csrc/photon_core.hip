@@ -429,19 +429,23 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 // generations lasted about G + 0.9 lifetimes -- one GPU's eighth of C3, 3.8 generations, ran at 81 % occupancy).
 // Here the grid is just large enough to fill the chip ONCE and every wave takes 64-ray groups from a queue until the
 // launch is served: a wave that finishes a group loads the next one itself, no slot waits for the dispatcher.
-// 64 queues, eight per XCD (workgroup i runs on XCD i % 8), each handing out the groups of its 8K-ray chunks in order, so
+// 32 queues, four per XCD (workgroup i runs on XCD i % 8), each handing out the groups of its 8K-ray chunks in order, so
 // rays that walk the same voxels still meet in one L2 (what xcd_remap did for the one-shot launch); the visiting order and
-// why 64 are at the loop.  Every wave leaves as soon as its fifteen queues are past their ends.
+// why four are at the loop.  Every wave leaves as soon as its eleven queues are past their ends.
 #ifndef PHOTON_MARCH_PERSISTENT
 #define PHOTON_MARCH_PERSISTENT 1
 #endif
 constexpr unsigned kQueueStride = 16;                           // u32 per queue counter: one 64-byte line each
-constexpr unsigned kQueues = 64;                                // 8 XCDs x 8 sub-queues
+#ifndef PHOTON_SUBQUEUES
+#define PHOTON_SUBQUEUES 4              // work queues per XCD (a power of two, <= 8); measured 1 / 2 / 4 / 8, see march_kernel
+#endif
+constexpr unsigned kSubQueues = PHOTON_SUBQUEUES;
+constexpr unsigned kQueues = 64;                                // room for 8 XCDs x 8 sub-queues
 [[maybe_unused]] constexpr unsigned kGroupsPerChunk = PHOTON_XCD_CHUNK * 4;      // 64-ray groups per 8K-ray chunk
 // The k-th group handed out by sub-queue `sub` of XCD `xcd`: chunk ((k / C) * 8 + sub) * 8 + xcd, group k % C of it.  Grows
 // with k, so the first k whose group lies past the launch ends the queue; every group belongs to exactly one (xcd, sub).
 __host__ __device__ inline unsigned march_queue_group(unsigned k, unsigned xcd, unsigned sub) {
-    return (((k / kGroupsPerChunk) * 8u + sub) * 8u + xcd) * kGroupsPerChunk + k % kGroupsPerChunk;
+    return (((k / kGroupsPerChunk) * kSubQueues + sub) * 8u + xcd) * kGroupsPerChunk + k % kGroupsPerChunk;
 }
 
 // The march kernel's arguments, read from the kernel-argument segment WHERE THEY ARE USED (scalar loads through a pointer
@@ -527,18 +531,23 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
     const unsigned lane = threadIdx.x & 63u;
     WaveTotals tot;
 #if PHOTON_MARCH_PERSISTENT
-    // 64 queues: XCD x (workgroup i runs on XCD i % 8) owns the 8K-ray chunks c with c % 8 == x, dealt over its eight
-    // sub-queues by (c / 8) % 8.  One counter per queue, a cache line apart: with one queue per XCD a launch whose groups
-    // are no work (every ray misses the volume: the reference's sample BOS case, ~1e6 groups) spent its time on returning
-    // atomics to eight addresses (one-shot launch 7.6 ms, one queue per XCD 9.1, sixty-four queues 7.8).  A wave serves its
-    // home sub-queue, then the other seven of its XCD (between them the XCD's waves drain all eight: every group is
-    // taken), then the same sub-queue of the seven other XCDs (balance at the end of the launch).  Taking several groups
-    // per access instead was tried and dropped: wherever trivial and real groups mix (doomed lens samples of a PIV
-    // launch) a wave ends up holding dozens of real groups while the chip drains (C5 quarter 38.6 -> 92 ms).
-    const unsigned home_x = blockIdx.x & 7u, home_s = (blockIdx.x >> 3) & 7u;
-    for (unsigned step = 0; step < 15u; step++) {
-        const unsigned x = step < 8u ? home_x : ((home_x + step - 7u) & 7u);
-        const unsigned sub = step < 8u ? ((home_s + step) & 7u) : home_s;
+    // 32 queues: XCD x (workgroup i runs on XCD i % 8) owns the 8K-ray chunks c with c % 8 == x, dealt over its four
+    // sub-queues by (c / 8) % 4; one counter per queue, a cache line apart.  A wave serves its home sub-queue, then the
+    // other three of its XCD (between them the XCD's waves drain all four: every group is taken), then the same sub-queue
+    // of the seven other XCDs (balance at the end of the launch).  How many sub-queues (same box, 1 / 2 / 4 / 8 per XCD):
+    //   * few queues = returning atomics to few addresses: a launch whose groups are no work (every ray misses the
+    //     volume: the reference's sample BOS case, ~1e6 groups) takes 9.3 / 8.2 / 7.7 / 7.7 ms per call (one-shot: 7.6);
+    //   * many queues = each served by few waves, so the eight groups that carry ONE source's rays start further apart in
+    //     time, walk the volume at different depths and share fewer L2 lines: HBM traffic of the C3 launch 1.9 / 2.0 /
+    //     2.6 / 4.8 GB (one-shot, where a whole generation walks in lockstep: 1.3); the march time does not care (62.1 /
+    //     61.9 / 62.3 / 62.1 ms).
+    // Taking several groups per access instead of adding queues was tried and dropped: wherever trivial and real groups
+    // mix (doomed lens samples of a PIV launch) a wave ends up holding dozens of real groups while the chip drains (C5
+    // quarter 38.6 -> 92 ms).
+    const unsigned home_x = blockIdx.x & 7u, home_s = (blockIdx.x >> 3) & (kSubQueues - 1u);
+    for (unsigned step = 0; step < kSubQueues + 7u; step++) {
+        const unsigned x = step < kSubQueues ? home_x : ((home_x + step - (kSubQueues - 1u)) & 7u);
+        const unsigned sub = step < kSubQueues ? ((home_s + step) & (kSubQueues - 1u)) : home_s;
         while (true) {
             unsigned k = 0;
             if (lane == 0) k = atomicAdd(&march_args()->queue[(sub * 8u + x) * kQueueStride], 1u);
@@ -1515,7 +1524,7 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
     return 0;
 }
 
-unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub) { return march_queue_group(k, xcd & 7u, sub & 7u); }
+unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub) { return march_queue_group(k, xcd & 7u, sub & (kSubQueues - 1u)); }
 
 int photon_scene_set_source_base(photon_scene_t *s, int64_t first_source) {
     if (!s || first_source < 0) return 1;

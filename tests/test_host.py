@@ -96,7 +96,7 @@ def test_tiff_and_raw_writers_round_trip(tmp_path):
 
 
 def test_march_work_queues_partition_every_launch():
-    """The 64 work queues of the persistent march (8 XCDs x 8 sub-queues): for any number of 64-ray groups every group
+    """The work queues of the persistent march (8 XCDs x 4 sub-queues): for any number of 64-ray groups every group
     below it is handed out by exactly one queue, each queue hands its groups out in increasing order (so the first one
     past the end ends the queue), and consecutive groups of an 8K-ray chunk come from ONE queue (L2 locality).  Host
     restatement of the kernel's own function, through the C-ABI; no GPU needed."""
@@ -109,7 +109,7 @@ def test_march_work_queues_partition_every_launch():
     for n_groups in (1, 127, 128, 129, 1023, 8 * 128 + 5, 64 * 128, 64 * 128 + 1, 19532):
         seen = np.zeros(n_groups, np.int32)
         for x in range(8):
-            for sub in range(8):
+            for sub in range(4):
                 last, k = -1, 0
                 while True:
                     g = f(k, x, sub)
@@ -118,6 +118,6 @@ def test_march_work_queues_partition_every_launch():
                     if g >= n_groups:
                         break
                     seen[g] += 1
-                    assert (g // 128) % 8 == x and (g // 128 // 8) % 8 == sub
+                    assert (g // 128) % 8 == x and (g // 128 // 8) % 4 == sub
                     k += 1
         assert (seen == 1).all(), n_groups
