@@ -194,8 +194,8 @@ typedef struct photon_trace_stats_t {
                                        waves x 100 MHz (the chip lowers its clock under load, differently from device to
                                        device); 0 without a volume */
     uint32_t traces;                /* photon_trace calls these numbers cover (1, or the calls of a statistics window) */
-    float march_wave_ms;            /* mean lifetime of a march wave (64 rays), from the same stamps: a launch of W waves lasts
-                                       about W / (waves resident on the chip) of these */
+    float march_wave_ms;            /* mean time a march wave spends on one 64-ray group, from the same stamps: a launch of G
+                                       groups lasts about G / (waves resident on the chip) of these */
 } photon_trace_stats_t;
 
 /* Select the GPU this thread's subsequent photon_* calls use (hipSetDevice). */

@@ -1810,7 +1810,7 @@ static int read_counters(photon_scene *scene, bool have_volume, photon_trace_sta
     stats->rays_marched = have_volume ? c[CNT_MARCHED] : 0;
     // s_memtime ticks per s_memrealtime tick (100 MHz), over all waves of the march: the clock the kernel ran at
     stats->shader_clock_mhz = c[CNT_REAL] ? (float)((double)c[CNT_CLK] / (double)c[CNT_REAL] * 100.0) : 0.f;
-    // mean lifetime of a march wave (64 rays): with 5 waves per SIMD a launch lasts about (waves / 5120) lifetimes
+    // mean time a wave spends on one 64-ray group: with 5 waves per SIMD a launch lasts about (groups / 5120) of these
     stats->march_wave_ms = c[CNT_MARCHED] ? (float)((double)c[CNT_REAL] * 1e-5 / ((double)(c[CNT_MARCHED] + 63) / 64.0)) : 0.f;
     return 0;
 }
