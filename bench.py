@@ -171,10 +171,13 @@ def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source
     for name in ("C0", "C2"):                            # PIV, no volume (BASELINE.json configs[0], configs[1])
         c = scenes.config(name)
         o.render(c)                                      # warm-up
-        t0 = time.perf_counter()
-        o.render(c)
-        d = time.perf_counter() - t0
-        legs[name] = {"rays": c.num_rays, "ms": round(d * 1e3, 2), "Mrays_per_s": round(c.num_rays / d * 1e-6, 3)}
+        times = []
+        for _ in range(5):                               # median of 5 runs after 1 warm-up
+            t0 = time.perf_counter()
+            o.render(c)
+            times.append(time.perf_counter() - t0)
+        d = sorted(times)[2]
+        legs[name] = {"rays": c.num_rays, "ms": round(d * 1e3, 2), "Mrays_per_s": round(c.num_rays / d * 1e-6, 3), "runs": 5}
     rays = n_src * rays_per_source
     return {"value": rate, "unit": "Mrays/s", "cores": o.num_threads(), "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{rays} rays ({n_src} sources x {rays_per_source}) of the same scene and volume, ray loop only "
