@@ -45,6 +45,11 @@ LDS_PEAK_GBS = 150000.0          # aggregate ds_read_b64/b128 rate with every CU
 LDS_BYTES_PER_CLK = 256 * 256    # ds_read_b128: 256 B/clk/CU x 256 CUs -- times the MEASURED shader clock = peak at that clock
 VALU_F32_PEAK_TFLOPS = 157.3     # vector f32 (256 CUs x 4 SIMD x 32 lanes/clk FMA x 2.4 GHz x 2)
 TEXELS_PER_SAMPLE = {1: 8, 2: 64}
+# VALU instructions per wave-sample of the march kernels, from the SQ_INSTS_VALU counter (profiles/r03_c_*_pmc.json), keyed by
+# (algorithm, interpolation); and the issue rate a stream of independent v_fma_f32 reaches on this chip at four or more
+# waves per SIMD (tools/ubench/fma_rate.hip, profiles/r03_ubench_fma_rate.log), in cycles per instruction per SIMD
+VALU_PER_WAVE_SAMPLE = {(2, 2): 413.9, (2, 1): 145.8, (1, 2): 446.3, (1, 1): 145.9}
+VALU_PRACTICAL_CYCLES_PER_INST = 2.17
 
 
 def parse_args(argv=None):
@@ -489,6 +494,16 @@ def main():
                         "the f32 VALU (valu_f32) is the co-limiter and the board's power cap (board_power) the limit behind both.  HBM only "
                         "sees the ray state and the touched texels (hbm.traffic, measured by rocprofv3 --pmc in this run)"}
 
+    # VALU issue: the march is bound by how fast its instruction stream issues -- cycles each instruction gets, from the kernel's
+    # own time and clock, against what a stream of independent FMAs reaches
+    n_inst = VALU_PER_WAVE_SAMPLE.get((args.algorithm, interp))
+    if n_inst and clock_mhz > 0 and samples > 0 and march_ms_avg > 0:
+        simds = 4 * 256
+        cyc = march_ms_avg * 1e-3 * clock_mhz * 1e6 * simds / (samples / 64.0 * n_inst)
+        roofline["valu_issue"] = {"insts_per_wave_sample": n_inst, "cycles_per_inst": round(cyc, 3),
+                                  "practical_cycles_per_inst": VALU_PRACTICAL_CYCLES_PER_INST,
+                                  "frac": round(VALU_PRACTICAL_CYCLES_PER_INST / cyc, 4),
+                                  "what": "instruction count from SQ_INSTS_VALU (profiles/), time and clock measured in this run"}
     out = None
     if rank == 0:
         roofline["hbm"]["copy_measured_gbs"] = round(lib.measure_copy_gbs(), 1)       # float4 streaming copy, read + write
