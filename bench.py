@@ -66,6 +66,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-rays", type=int, default=1000000, help="rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--check", action="store_true", help="also verify a slice of the image against the oracle")
+    ap.add_argument("--clock-trace", type=int, default=0, metavar="W",
+                    help="after the timed loop, run the same number of steps again in windows of W steps and report the march's "
+                         "shader clock, kernel time and board power per window (does a short launch clock lower, or only ramp?)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the wave-timing pass (roofline.march_profile)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N ranks SHARING device 0, gloo reduce of host copies: exercises the N > 1 logic of this script on a "
                          "one-GPU box (RCCL cannot put two ranks on one GPU); the line is marked as a rehearsal, not a measurement")
@@ -441,6 +445,40 @@ def main():
         clock_mhz = float(st.shader_clock_mhz)
         wave_ms = float(st.march_wave_ms)
     rays_rank = (src_end - src_begin) * args.rays_per_source
+
+    # ---- side passes AFTER the timed region (never part of `value`) -------------------------------------------------
+    # wave timing of the march launch: start-up ramp and drain (photon_scene_set_march_profile), over a few more steps
+    march_profile = None
+    if rank == 0 and windowed and lib.has_march_profile and not args.no_profile:
+        scene.set_march_profile(True)
+        scene.stats_begin(stream)
+        for _ in range(min(args.steps, 10)):
+            step(False)
+        scene.stats_end(stream)
+        march_profile = scene.march_profile()
+        scene.set_march_profile(False)
+    # the march's clock over time: windows of W steps, each read back on its own
+    clock_trace = None
+    if rank == 0 and windowed and args.clock_trace > 0 and world == 1:
+        clock_trace = []
+        left = args.steps
+        while left > 0:
+            n_w = min(args.clock_trace, left)
+            left -= n_w
+            pw = PowerSampler(lib.pci_bus_id())
+            scene.stats_begin(stream)
+            torch.cuda.synchronize()
+            pw.start()
+            tw = time.perf_counter()
+            for _ in range(n_w):
+                step(False)
+            stw = scene.stats_end(stream)
+            dtw = time.perf_counter() - tw
+            pww = pw.stop()
+            clock_trace.append({"steps": n_w, "clock_mhz": round(float(stw.shader_clock_mhz), 1),
+                                "kernel_ms": round(stw.march_ms / max(int(stw.traces), 1), 3),
+                                "ms_per_step": round(dtw / n_w * 1e3, 3), "wave_lifetime_ms": round(float(stw.march_wave_ms), 4),
+                                "power_w": pww["median_w"] if pww else None})
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -478,6 +516,7 @@ def main():
                 "wave_lifetime_ms": round(wave_ms, 4) if wave_ms > 0 else None,
                 "wave_generations": round(rays_rank / 64 / (256 * 4 * 5), 2),
                 "board_power": power_w,
+                "march_profile": march_profile, "clock_trace": clock_trace,
                 "peak_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
                 "frac_at_clock": round(achieved / peak_at_clock, 4) if peak_at_clock else None,
                 "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),

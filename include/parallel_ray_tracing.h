@@ -311,6 +311,27 @@ int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_trac
 int photon_scene_stats_begin(photon_scene_t *scene, void *stream);
 int photon_scene_stats_end(photon_scene_t *scene, void *stream, photon_trace_stats_t *stats);
 
+/* Wave timing of the march launches (measurement; off by default, costs a handful of atomics per wave when on).  With
+ * it on, every march launch after the statistics counters were last zeroed (photon_trace with stats, or
+ * photon_scene_stats_begin) records -- on the device's constant 100 MHz clock -- when its first wave entered, when each
+ * wave started its first 64-ray group and when it left; photon_scene_march_profile returns the means over those launches
+ * (the first 64 of them), all times counted from the first wave's entry:
+ *   span_ms          until the last wave left (the launch as the chip saw it)
+ *   start_mean/max   until a wave started its first group (dispatch ramp, argument loads, first queue access)
+ *   end_min/mean     until a wave left; span_ms - end_mean_ms = the DRAIN, the average time a wave slot stood empty at the
+ *                    end of the launch while the last groups finished
+ * The caller sets struct_size = sizeof(photon_march_profile_t) (the library refuses a smaller struct than it knows). */
+typedef struct photon_march_profile_t {
+    uint32_t struct_size;
+    uint32_t launches;              /* march launches the means cover (0: profile off, or no launch since the reset) */
+    uint32_t waves;                 /* waves that served at least one group, mean per launch */
+    float span_ms;
+    float start_mean_ms, start_max_ms;
+    float end_min_ms, end_mean_ms;
+} photon_march_profile_t;
+int photon_scene_set_march_profile(photon_scene_t *scene, int on);
+int photon_scene_march_profile(photon_scene_t *scene, photon_march_profile_t *out);
+
 /* March-only entry point for parity tests: n rays (host arrays pos/dir f32[n][3], world
  * frame) through trace_rays_through_density_gradients (.h:1455-1544); results in place,
  * steps (optional) receives the per-ray completed iteration count. */

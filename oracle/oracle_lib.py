@@ -43,13 +43,22 @@ def build_oracle(force: bool = False) -> str:
     return ORACLE_SO
 
 
+ORACLE_FMA_SO = os.path.join(ORACLE_DIR, "libphoton_oracle_fma.so")
+
+
+def build_oracle_fma() -> str:
+    """The contracted-FMA build of the same source (oracle/Makefile, target `fma`): a sensitivity probe, never the reference."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s", "fma"], check=True, stdout=sys.stderr)
+    return ORACLE_FMA_SO
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
 class Oracle:
-    def __init__(self):
-        self.lib = ctypes.CDLL(build_oracle())
+    def __init__(self, contracted: bool = False):
+        self.lib = ctypes.CDLL(build_oracle_fma() if contracted else build_oracle())
         L = self.lib
         self._start = bind_start_ray_tracing(L, "oracle_start_ray_tracing",
                                              [ctypes.c_int, ctypes.c_int, ctypes.POINTER(oracle_stats_t)])

@@ -462,6 +462,7 @@ struct MarchArgs {
     unsigned long long ray_base;
     InterDump idump;
     unsigned *queue;
+    unsigned long long *profile;        // this launch's wave-timing slots (photon_scene_set_march_profile), or nullptr
 };
 typedef const __attribute__((address_space(4))) MarchArgs *MarchArgsPtr;
 template <class T>
@@ -476,10 +477,28 @@ __device__ __forceinline__ MarchArgsPtr march_args() {
     return p;
 }
 
+// Wave timing of a march launch (photon_scene_set_march_profile; off by default): when the first wave entered, when each
+// wave started its first group and when it left, on the constant 100 MHz clock -- what tells a launch's start-up cost
+// (dispatch, cold caches) from its drain (the last groups finishing one by one while the rest of the chip idles).
+// kProfileSub copies per launch (a cache line each, chosen by workgroup) so that the stamps of a chip's worth of waves
+// do not serialise on one address; minima are kept as maxima of the complement, so a slot starts from zeros.
+enum { PF_ENTER_NEGMIN = 0, PF_START_NEGMIN, PF_START_SUM, PF_START_MAX, PF_END_NEGMIN, PF_END_SUM, PF_END_MAX, PF_WAVES, PF_N };
+constexpr unsigned kProfileLaunches = 64, kProfileSub = 64;
+__device__ __forceinline__ unsigned long long real_time() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long *profile_slot() {
+    unsigned long long *p = march_args()->profile;
+    return p ? p + (size_t)(blockIdx.x % kProfileSub) * PF_N : nullptr;
+}
+
 // What a march wave accumulates over the groups it serves (wave-uniform: SGPRs) and adds to the counters once, at its end.
 struct WaveTotals {
     WaveCount mc{0u, 0u};
     unsigned n_marched = 0;                                     // rays that entered the march (not skipped as doomed)
+    unsigned groups = 0;                                        // groups served
     unsigned long long clk_sum = 0, real_sum = 0;               // shader-clock / 100 MHz ticks spent in groups
 };
 
@@ -488,6 +507,12 @@ template <int ALGO, int INTERP, bool SAVE, bool NOISE>
 __device__ __forceinline__ void march_group(unsigned group, unsigned n_rays, f4 *tile, WaveTotals &tot) {
     unsigned long long clk0, real0, clk1, real1;
     clock_stamp(clk0, real0);
+    if (tot.groups++ == 0) {                                    // wave-uniform: this wave's first group
+        unsigned long long *pf = profile_slot();
+        if (pf && (threadIdx.x & 63u) == 0) {
+            atomicMax(&pf[PF_START_NEGMIN], ~real0); atomicAdd(&pf[PF_START_SUM], real0); atomicMax(&pf[PF_START_MAX], real0);
+        }
+    }
     const unsigned r = group * 64u + (threadIdx.x & 63u);
     const bool has_ray = r < n_rays;
     f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
@@ -530,6 +555,10 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
     f4 *const tile = tiles[threadIdx.x >> 6];
     const unsigned lane = threadIdx.x & 63u;
     WaveTotals tot;
+    {
+        unsigned long long *pf = profile_slot();
+        if (pf && lane == 0) atomicMax(&pf[PF_ENTER_NEGMIN], ~real_time());
+    }
 #if PHOTON_MARCH_PERSISTENT
     // 32 queues: XCD x (workgroup i runs on XCD i % 8) owns the 8K-ray chunks c with c % 8 == x, dealt over its four
     // sub-queues by (c / 8) % 4; one counter per queue, a cache line apart.  A wave serves its home sub-queue, then the
@@ -565,6 +594,14 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
         if (group < (n_rays + 63u) / 64u) march_group<ALGO, INTERP, SAVE, NOISE>(group, n_rays, tile, tot);
     }
 #endif
+    if (tot.groups) {                                           // wave-uniform
+        unsigned long long *pf = profile_slot();
+        if (pf && lane == 0) {                                  // the wave leaves a few queue visits after its last group
+            const unsigned long long t = real_time();
+            atomicMax(&pf[PF_END_NEGMIN], ~t); atomicAdd(&pf[PF_END_SUM], t); atomicMax(&pf[PF_END_MAX], t);
+            atomicAdd(&pf[PF_WAVES], 1ull);
+        }
+    }
     if (lane == 0) {
         unsigned long long *slot = counter_slot(march_args()->counters);
         if (tot.mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)tot.mc.iterations);
@@ -825,6 +862,8 @@ struct photon_scene {
     unsigned long long *d_counters = nullptr;
     unsigned *d_queue = nullptr;        // the march's work queues: 64 counters (8 XCDs x 8 sub-queues), a cache line apart
     int num_cus = 256;                  // compute units of the scene's device (size of the persistent march grid)
+    unsigned long long *d_profile = nullptr;    // wave-timing slots of the march launches (photon_scene_set_march_profile), or nullptr
+    unsigned prof_next = 0;             // march launches since the slots were last zeroed
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // statistics window (photon_scene_stats_begin / _end): traces inside it record their events and leave the counters
@@ -1251,6 +1290,7 @@ void photon_scene_free(photon_scene_t *s) {
     if (s->ws.radiance) (void)hipFree(s->ws.radiance);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_queue) (void)hipFree(s->d_queue);
+    if (s->d_profile) (void)hipFree(s->d_profile);
     if (s->d_acc) (void)hipFree(s->d_acc);
     for (auto &p : s->perms) if (p.d_perm) (void)hipFree(p.d_perm);
     photon_sort_scratch_free(&s->sort_scratch);
@@ -1713,7 +1753,10 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2))
             PH_CHECK(hipMemsetAsync(s->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned), stream));
         if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
-        const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue};
+        unsigned long long *profile = nullptr;                  // wave timing of this launch, while there are free slots
+        if (s->d_profile && s->prof_next < kProfileLaunches && (algorithm == 1 || algorithm == 2))
+            profile = s->d_profile + (size_t)(s->prof_next++) * kProfileSub * PF_N;
+        const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue, profile};
 #define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), mgrid, mblock, 0, stream, margs)
         if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
@@ -1796,6 +1839,81 @@ static int trace_accumulate(photon_scene *scene, const photon_volume *vol, int r
     return 0;
 }
 
+// Wave timing of the march launches (off by default): the slots are zeroed where the statistics counters are, and every
+// march launch after that takes the next one.
+static int profile_reset(photon_scene *s, hipStream_t stream) {
+    s->prof_next = 0;
+    if (s->d_profile) PH_CHECK(hipMemsetAsync(s->d_profile, 0, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long), stream));
+    return 0;
+}
+
+extern "C" int photon_scene_set_march_profile(photon_scene_t *scene, int on) {
+    if (!scene) return 1;
+    return guarded("photon_scene_set_march_profile", [&]() -> int {
+        if (on && !scene->d_profile) {
+            PH_CHECK(hipMalloc((void **)&scene->d_profile, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
+            PH_CHECK(hipMemset(scene->d_profile, 0, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
+        } else if (!on && scene->d_profile) {
+            PH_CHECK(hipDeviceSynchronize());
+            (void)hipFree(scene->d_profile);
+            scene->d_profile = nullptr;
+        }
+        scene->prof_next = 0;
+        return 0;
+    });
+}
+
+extern "C" int photon_scene_march_profile(photon_scene_t *scene, photon_march_profile_t *out) {
+    if (!scene || !out || out->struct_size < sizeof(photon_march_profile_t)) {
+        fprintf(stderr, "photon: photon_scene_march_profile: bad arguments (set struct_size = sizeof(photon_march_profile_t))\n");
+        return 1;
+    }
+    return guarded("photon_scene_march_profile", [&]() -> int {
+        const uint32_t size = out->struct_size;
+        memset(out, 0, sizeof *out);
+        out->struct_size = size;
+        if (!scene->d_profile || scene->prof_next == 0) return 0;
+        const unsigned launches = std::min(scene->prof_next, kProfileLaunches);
+        std::vector<unsigned long long> h((size_t)launches * kProfileSub * PF_N);
+        PH_CHECK(hipDeviceSynchronize());
+        PH_CHECK(hipMemcpy(h.data(), scene->d_profile, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double span = 0, start_mean = 0, start_max = 0, end_min = 0, end_mean = 0, waves_sum = 0;
+        unsigned used = 0;
+        for (unsigned l = 0; l < launches; l++) {
+            unsigned long long enter_min = ~0ull, start_min = ~0ull, start_max_t = 0, end_min_t = ~0ull, end_max_t = 0, waves = 0;
+            unsigned long long start_sum = 0, end_sum = 0;       // sums of absolute stamps: modulo 2^64, differences below are exact
+            for (unsigned k = 0; k < kProfileSub; k++) {
+                const unsigned long long *q = &h[((size_t)l * kProfileSub + k) * PF_N];
+                if (q[PF_ENTER_NEGMIN]) enter_min = std::min(enter_min, ~q[PF_ENTER_NEGMIN]);
+                if (!q[PF_WAVES]) continue;
+                start_min = std::min(start_min, ~q[PF_START_NEGMIN]);
+                start_max_t = std::max(start_max_t, q[PF_START_MAX]);
+                end_min_t = std::min(end_min_t, ~q[PF_END_NEGMIN]);
+                end_max_t = std::max(end_max_t, q[PF_END_MAX]);
+                start_sum += q[PF_START_SUM]; end_sum += q[PF_END_SUM]; waves += q[PF_WAVES];
+            }
+            if (!waves) continue;
+            const double tick_ms = 1e-5;                         // 100 MHz
+            used++;
+            waves_sum += (double)waves;
+            span += (double)(end_max_t - enter_min) * tick_ms;
+            start_mean += (double)(long long)(start_sum - waves * enter_min) / (double)waves * tick_ms;
+            start_max += (double)(start_max_t - enter_min) * tick_ms;
+            end_min += (double)(end_min_t - enter_min) * tick_ms;
+            end_mean += (double)(long long)(end_sum - waves * enter_min) / (double)waves * tick_ms;
+        }
+        if (!used) return 0;
+        out->launches = used;
+        out->waves = (uint32_t)(waves_sum / used + 0.5);
+        out->span_ms = (float)(span / used);
+        out->start_mean_ms = (float)(start_mean / used);
+        out->start_max_ms = (float)(start_max / used);
+        out->end_min_ms = (float)(end_min / used);
+        out->end_mean_ms = (float)(end_mean / used);
+        return 0;
+    });
+}
+
 // Sum the counter slots into stats (the caller has made sure the device is done with them).
 static int read_counters(photon_scene *scene, bool have_volume, photon_trace_stats_t *stats) {
     std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
@@ -1834,6 +1952,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
         size_t w0 = 0, w1 = 0;
         if (stats) {
             PH_CHECK(hipMemsetAsync(scene->d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long), stream));
+            { const int rc = profile_reset(scene, stream); if (rc) return rc; }
             PH_CHECK(hipEventRecord(scene->ev[0], stream));
         } else if (scene->win_open) {
             { const int rc = window_event(scene, &w0); if (rc) return rc; }
@@ -1873,6 +1992,7 @@ extern "C" int photon_scene_stats_begin(photon_scene_t *scene, void *stream_p) {
     return guarded("photon_scene_stats_begin", [&]() -> int {
         hipStream_t stream = (hipStream_t)stream_p;
         PH_CHECK(hipMemsetAsync(scene->d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long), stream));
+        { const int rc = profile_reset(scene, stream); if (rc) return rc; }
         scene->win_used = 0;
         scene->win_march.clear();
         scene->win_total.clear();

@@ -21,7 +21,8 @@ DECLARED_SYMBOLS = (
     "start_ray_tracing", "photon_set_device", "photon_device_pci_bus_id", "photon_rand_table", "photon_volume_load_nrrd",
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
     "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_march_queue_group", "photon_trace",
-    "photon_scene_stats_begin", "photon_scene_stats_end", "photon_trace_volume_rays", "photon_version",
+    "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_set_march_profile", "photon_scene_march_profile",
+    "photon_trace_volume_rays", "photon_version",
     # section 3: scene generation on the device
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
     "photon_scene_create_from_sources", "photon_volume_gaussian", "photon_density_gaussian_write_nrrd",
@@ -46,6 +47,17 @@ class photon_trace_stats_t(ctypes.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class photon_march_profile_t(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("launches", ctypes.c_uint32), ("waves", ctypes.c_uint32),
+                ("span_ms", ctypes.c_float), ("start_mean_ms", ctypes.c_float), ("start_max_ms", ctypes.c_float),
+                ("end_min_ms", ctypes.c_float), ("end_mean_ms", ctypes.c_float)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "struct_size"}
+        d["drain_ms"] = d["span_ms"] - d["end_mean_ms"]
+        return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
 
 
 class PhotonError(RuntimeError):
@@ -145,6 +157,10 @@ class PhotonLibrary:
         if self.has_stats_window:
             L.photon_scene_stats_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             L.photon_scene_stats_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(photon_trace_stats_t)]
+        self.has_march_profile = hasattr(L, "photon_scene_march_profile")  # round 4
+        if self.has_march_profile:
+            L.photon_scene_set_march_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            L.photon_scene_march_profile.argtypes = [ctypes.c_void_p, ctypes.POINTER(photon_march_profile_t)]
         L.photon_trace_volume_rays.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p]
         L.photon_sources_bos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -415,6 +431,17 @@ class Scene:
         self._lib._check(self._lib.lib.photon_scene_stats_end(self.handle, ctypes.c_void_p(int(stream)) if stream else None,
                                                               ctypes.byref(stats)), "photon_scene_stats_end")
         return stats
+
+    def set_march_profile(self, on: bool):
+        """Record wave entry / first-group / exit times of the march launches (measurement; off by default)."""
+        self._lib._check(self._lib.lib.photon_scene_set_march_profile(self.handle, int(bool(on))), "photon_scene_set_march_profile")
+
+    def march_profile(self) -> dict:
+        """Means over the march launches since the statistics were last reset (see photon_march_profile_t)."""
+        out = photon_march_profile_t()
+        out.struct_size = ctypes.sizeof(photon_march_profile_t)
+        self._lib._check(self._lib.lib.photon_scene_march_profile(self.handle, ctypes.byref(out)), "photon_scene_march_profile")
+        return out.as_dict()
 
     def set_noise(self, add_pos_noise=False, pos_noise_std=0.0, add_ngrad_noise=False, ngrad_noise_std=0.0, seed=0):
         self._lib._check(self._lib.lib.photon_scene_set_noise(self.handle, int(bool(add_pos_noise)), float(pos_noise_std),
