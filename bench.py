@@ -45,11 +45,11 @@ LDS_PEAK_GBS = 150000.0          # aggregate ds_read_b64/b128 rate with every CU
 LDS_BYTES_PER_CLK = 256 * 256    # ds_read_b128: 256 B/clk/CU x 256 CUs -- times the MEASURED shader clock = peak at that clock
 VALU_F32_PEAK_TFLOPS = 157.3     # vector f32 (256 CUs x 4 SIMD x 32 lanes/clk FMA x 2.4 GHz x 2)
 TEXELS_PER_SAMPLE = {1: 8, 2: 64}
-# VALU instructions per wave-sample of the march kernels, from the SQ_INSTS_VALU counter (profiles/r03_c_*_pmc.json), keyed by
-# (algorithm, interpolation); and the issue rate a stream of independent v_fma_f32 reaches on this chip at four or more
-# waves per SIMD (tools/ubench/fma_rate.hip, profiles/r03_ubench_fma_rate.log), in cycles per instruction per SIMD
-VALU_PER_WAVE_SAMPLE = {(2, 2): 413.9, (2, 1): 145.8, (1, 2): 446.3, (1, 1): 145.9}
+# the issue rate a stream of independent v_fma_f32 reaches on this chip at four or more waves per SIMD
+# (tools/ubench/fma_rate.hip, profiles/r03_ubench_fma_rate.log), in cycles per instruction per SIMD.  The march's own
+# instruction counts are MEASURED in the run (SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_INSTS_SALU, measure_counters).
 VALU_PRACTICAL_CYCLES_PER_INST = 2.17
+SIMDS = 4 * 256
 
 
 def parse_args(argv=None):
@@ -70,6 +70,8 @@ def parse_args(argv=None):
                     help="after the timed loop, run the same number of steps again in windows of W steps and report the march's "
                          "shader clock, kernel time and board power per window (does a short launch clock lower, or only ramp?)")
     ap.add_argument("--no-profile", action="store_true", help="skip the wave-timing pass (roofline.march_profile)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the GPU legs of the other BASELINE configs (gpu_other_configs)")
+    ap.add_argument("--c4", action="store_true", help="add C4 whole (1e8 rays, 512^3, ~3 s and 5 GiB of HBM) to gpu_other_configs")
     ap.add_argument("--rehearse", action="store_true",
                     help="N ranks SHARING device 0, gloo reduce of host copies: exercises the N > 1 logic of this script on a "
                          "one-GPU box (RCCL cannot put two ranks on one GPU); the line is marked as a rehearsal, not a measurement")
@@ -244,22 +246,24 @@ class PowerSampler:
                 "what": "board power over the timed loop (hwmon power1_input, an average the firmware publishes)"}
 
 
-def measure_hbm_traffic(args, kernel_tag: str):
-    """HBM bytes per launch of the march kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE each in its own run, no tracing alongside) over a short child run of this same bench, corrected
-    as MI355X_MICROARCH.md section HBM prescribes for gfx950 (FETCH_SIZE x2 for wide coalesced reads; both in
-    KiB).  Returns (bytes or None, detail dict).  The children are ordinary child processes of this one."""
+def measure_counters(args, kernel_tag: str):
+    """Counters of the march kernel, measured NOW by rocprofv3 --pmc passes over short child runs of this same bench (no
+    tracing alongside; each set in its own run): FETCH_SIZE and WRITE_SIZE -> HBM bytes per launch, corrected as
+    MI355X_MICROARCH.md section HBM prescribes for gfx950 (FETCH_SIZE x2 for wide coalesced reads; both in KiB), and
+    SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_INSTS_SALU -> the instruction counts the issue-rate figures are computed from.
+    Returns (traffic bytes or None, instruction counts per launch or None, detail dict).  The children are ordinary child
+    processes of this one."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, {"source": "unavailable: rocprofv3 not found"}
+        return None, None, {"source": "unavailable: rocprofv3 not found"}
     if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return None, {"source": "unavailable: this run is itself under a profiler (no nested rocprofv3 passes)"}
+        return None, None, {"source": "unavailable: this run is itself under a profiler (no nested rocprofv3 passes)"}
     means = {}
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory(prefix="photon_pmc_", dir="/tmp") as tmp:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU")):
+            out = os.path.join(tmp, counters[0])
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-sample-rays", "0", "--no-traffic",
                    "--interp", args.interp, "--algorithm", str(args.algorithm), "--volume", str(args.volume), "--dots", str(args.dots),
                    "--rays-per-source", str(args.rays_per_source)]
@@ -269,22 +273,76 @@ def measure_hbm_traffic(args, kernel_tag: str):
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
             except subprocess.TimeoutExpired:
-                return None, {"source": f"unavailable: rocprofv3 --pmc {counter} pass timed out"}
-            vals = []
+                return None, None, {"source": f"unavailable: rocprofv3 --pmc {counters[0]} pass timed out"}
+            vals = {c: [] for c in counters}
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            vals.append(float(row["Counter_Value"]))
-            if r.returncode != 0 or not vals:
+                        if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] in vals:
+                            vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not all(vals.values()):
                 tail = r.stdout.decode("utf-8", "replace")[-300:].replace("\n", " | ")
-                return None, {"source": f"unavailable: rocprofv3 --pmc {counter} pass gave no rows (rc {r.returncode}): {tail}"}
-            means[counter] = sum(vals) / len(vals)
+                if counters[0].startswith("SQ_"):       # the traffic figure stands without the instruction counts
+                    means["insts_error"] = f"rocprofv3 --pmc {' '.join(counters)} gave no rows (rc {r.returncode}): {tail}"
+                    continue
+                return None, None, {"source": f"unavailable: rocprofv3 --pmc {counters[0]} pass gave no rows (rc {r.returncode}): {tail}"}
+            for c in counters:
+                means[c] = sum(vals[c]) / len(vals[c])
     traffic = int(means["FETCH_SIZE"] * 1024 * 2 + means["WRITE_SIZE"] * 1024)
-    return traffic, {"source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per launch",
-                     "FETCH_SIZE_KiB": round(means["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(means["WRITE_SIZE"], 1),
-                     "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as counted",
-                     "seconds": round(time.perf_counter() - t0, 1)}
+    insts = {c: means[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU")} if "SQ_INSTS_VALU" in means else None
+    detail = {"source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per launch",
+              "FETCH_SIZE_KiB": round(means["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(means["WRITE_SIZE"], 1),
+              "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as counted",
+              "seconds": round(time.perf_counter() - t0, 1)}
+    if "insts_error" in means:
+        detail["insts_error"] = means["insts_error"]
+    return traffic, insts, detail
+
+
+def gpu_other_configs(lib, torch, workdir, with_c4):
+    """GPU legs of the configurations the headline line does not cover (BASELINE.json configs), device
+    resident like the headline: C2 (PIV, Mie, thick lens, 4-pixel splat, no volume), C3 with the trilinear sampler (the one
+    the reference executes, parallel_ray_tracing.cu:3330), C5 at a quarter of its size on one GPU (the incoherent launch:
+    full-aperture cones, lens-major order, doomed rays skipped), one GPU's eighth of C3 (the strong-scaling tail at N = 8)
+    and, on request, C4 whole.  Three traces each after one warm-up, statistics over the three."""
+    from photon_amd import scenes
+    legs = {}
+
+    def run(name, call, interp, what, reps=3):
+        scene = lib.scene_create(call)
+        vol = lib.volume_load_nrrd(call.density_grad_filename, interp) if call.simulate_density_gradients else None
+        H, W = call.image_shape
+        img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        algo = call.ray_tracing_algorithm
+        scene.trace(img.data_ptr(), vol, algo, stream=stream)                     # warm-up (lens-major: the device sort of the sources)
+        torch.cuda.synchronize()
+        scene.stats_begin(stream)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            img.zero_()
+            scene.trace(img.data_ptr(), vol, algo, stream=stream)
+        st = scene.stats_end(stream)
+        dt = (time.perf_counter() - t0) / reps
+        legs[name] = {"workload": what, "rays": call.num_rays, "ms": round(dt * 1e3, 3), "Mrays_per_s": round(call.num_rays / dt * 1e-6, 1),
+                      "kernel_ms": round(st.march_ms / reps, 3) if vol is not None else None,
+                      "clock_mhz": round(float(st.shader_clock_mhz), 1) if vol is not None else None,
+                      "rays_marched": int(st.rays_marched // reps), "rays_on_sensor": int(st.rays_on_sensor // reps), "traces": reps}
+        scene.free()
+        if vol is not None:
+            vol.free()
+
+    run("C2", scenes.config("C2"), 0, "PIV, 100 particles x 1e4 rays, Mie, thick lens, 4-pixel splat, no volume (one fused kernel)")
+    run("C3_trilinear", scenes.config("C3", workdir), 1,
+        "the headline job with the trilinear sampler and the texture unit's 8-bit weights (the reference's executed path)")
+    run("C3_eighth", scenes.bos_scene(n_dots=25, density_grad_filename=os.path.join(workdir, "bos_256.nrrd")), 2,
+        "one GPU's eighth of the headline job (1.25e6 rays, tricubic RK4): the strong-scaling tail at N = 8")
+    run("C5_quarter", scenes.config("C5", workdir, scale=0.25), 2,
+        "Mie PIV through the volume at 1/4 size: 2.5e5 polydisperse particles x 40 rays, 161^3 tricubic RK4, full-aperture cones "
+        "(lens-major order, doomed rays skipped)")
+    if with_c4:
+        run("C4", scenes.config("C4", workdir), 2, "C4 whole on one GPU: 2e5 sources x 500 = 1e8 rays, 512^3, tricubic RK4 (two launches)", reps=1)
+    return legs
 
 
 def time_abi_call(lib, call, interp):
@@ -448,12 +506,18 @@ def main():
 
     # ---- side passes AFTER the timed region (never part of `value`) -------------------------------------------------
     # wave timing of the march launch: start-up ramp and drain (photon_scene_set_march_profile), over a few more steps
+    side_image = torch.zeros_like(image) if rank == 0 else None
+
+    def trace_only():                   # a step without its collective, into an image of its own: rank 0 runs the side passes alone
+        side_image.zero_()
+        scene.trace(side_image.data_ptr(), volume, args.algorithm, src_begin, src_end, stream=stream, want_stats=False)
+
     march_profile = None
     if rank == 0 and windowed and lib.has_march_profile and not args.no_profile:
         scene.set_march_profile(True)
         scene.stats_begin(stream)
         for _ in range(min(args.steps, 10)):
-            step(False)
+            trace_only()
         scene.stats_end(stream)
         march_profile = scene.march_profile()
         scene.set_march_profile(False)
@@ -471,7 +535,7 @@ def main():
             pw.start()
             tw = time.perf_counter()
             for _ in range(n_w):
-                step(False)
+                trace_only()
             stw = scene.stats_end(stream)
             dtw = time.perf_counter() - tw
             pww = pw.stop()
@@ -496,53 +560,45 @@ def main():
     samples_per_iter = 3 if args.algorithm == 2 else 1
     bytes_per_ray = s_bar * samples_per_iter * TEXELS_PER_SAMPLE[interp] * 16 + a_bar * 8 + 40
     march_ms_avg = march_ms / args.steps
-    achieved = rays_rank * bytes_per_ray / (march_ms_avg * 1e-3) * 1e-9 if march_ms_avg > 0 else 0.0
+    kernel_s = march_ms_avg * 1e-3
+    texel_gbs = rays_rank * bytes_per_ray / kernel_s * 1e-9 if kernel_s > 0 else 0.0
     flops_per_sample = {"linear": 100.0, "cubic": 570.0}[args.interp]
     flops = samples * flops_per_sample + iters * 120.0
-    tflops = flops / (march_ms_avg * 1e-3) * 1e-12 if march_ms_avg > 0 else 0.0
+    tflops = flops / kernel_s * 1e-12 if kernel_s > 0 else 0.0
     compulsory = int(16 * args.volume ** 3 + 2 * 4 * H * W + 24 * call.num_sources)       # SURVEY.md 8d (this rank)
-    # The march serves its texels from LDS: a wave fetches each block once and every lane reads it back with
-    # broadcast ds_read_b128, so the ALGORITHMIC bytes of SURVEY 8d (S x 3 x T x 16 per ray) are exactly the bytes
-    # the kernel pulls through the LDS read pipe; they never were HBM bytes.  The bound that prices them is the LDS
-    # aggregate read rate; the f32 VALU (the separable FMA chain) is the co-limiter.  For the trilinear kernel (8
-    # texels per sample) neither pipe is near its peak: it is instruction-issue bound.
-    # The chip lowers its clock under load, by an amount that differs from device to device (guide, "DVFS give-back"): the
-    # march kernel stamps s_memtime / s_memrealtime per wave, so the line carries the clock it actually ran at and the
-    # fraction of the LDS read pipe AT THAT CLOCK -- the number that is comparable from box to box.
+    wave_samples = samples / 64.0
+    # What bounds the march.  SURVEY 8d's algorithmic bytes -- S x 3 x T x 16 per ray -- are the texel bytes the
+    # lanes' multiply-add chains consume; a wave fetches each texel block from memory ONCE and every lane reads it back from LDS
+    # (or, for a quarter of the tricubic taps, from a neighbour lane's register), so they never were HBM bytes: priced against
+    # HBM the fraction is ~16, and the measured HBM traffic is <1 % of the peak.  The kernel is bound by how fast its
+    # instruction stream ISSUES (measured: SQ_INSTS_VALU per launch, this run's kernel time and the clock the march stamped for
+    # itself, against the 2.17 cycles per instruction a stream of independent FMAs reaches) under the board's power cap, which
+    # sets that clock.  Top level = that bound; `texel_rate_vs_lds` keeps the SURVEY 8d figure against the LDS read roof.
     peak_at_clock = LDS_BYTES_PER_CLK * clock_mhz * 1e6 * 1e-9 if clock_mhz > 0 else None       # GB/s
-    roofline = {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / LDS_PEAK_GBS, 4), "traffic": None,
+    roofline = {"bound": "valu_issue+power", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+                "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
                 "clock_mhz": round(clock_mhz, 1) if clock_mhz > 0 else None,
                 "wave_lifetime_ms": round(wave_ms, 4) if wave_ms > 0 else None,
                 "wave_generations": round(rays_rank / 64 / (256 * 4 * 5), 2),
                 "board_power": power_w,
                 "march_profile": march_profile, "clock_trace": clock_trace,
-                "peak_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
-                "frac_at_clock": round(achieved / peak_at_clock, 4) if peak_at_clock else None,
-                "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
-                "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
-                "sensor_taps_per_ray": round(a_bar, 2), "rays_per_launch": rays_rank,
+                "valu_issue": None, "lds_pipe": None,
+                "texel_rate_vs_lds": {"what": "SURVEY 8d algorithmic bytes / kernel time against the LDS broadcast-read roof (256 B/clk/CU)",
+                                      "achieved": round(texel_gbs, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(texel_gbs / LDS_PEAK_GBS, 4),
+                                      "peak_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
+                                      "frac_at_clock": round(texel_gbs / peak_at_clock, 4) if peak_at_clock else None,
+                                      "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
+                                      "sensor_taps_per_ray": round(a_bar, 2), "rays_per_launch": rays_rank},
                 "valu_f32": {"achieved": round(tflops, 2), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "flops_per_sample": flops_per_sample},
                 "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "compulsory_bytes": compulsory, "traffic": None,
-                        "traffic_gbs": None, "frac": None},
-                "note": "bound = the pipe built to deliver SURVEY 8d's algorithmic bytes (texel bytes consumed by the multiply-add "
-                        "chain): LDS broadcast reads (guide: ~150 TB/s aggregate at 2.4 GHz; peak_at_clock = 256 B/clk/CU x 256 CUs x the "
-                        "clock the march measured for itself).  Since round 3, 16 of a tricubic sample's 64 texel reads are register "
-                        "broadcasts (DPP), so the LDS array is ~72 % busy while the delivered texel rate is frac_at_clock of the LDS roof; "
-                        "the f32 VALU (valu_f32) is the co-limiter and the board's power cap (board_power) the limit behind both.  HBM only "
-                        "sees the ray state and the touched texels (hbm.traffic, measured by rocprofv3 --pmc in this run)"}
-
-    # VALU issue: the march is bound by how fast its instruction stream issues -- cycles each instruction gets, from the kernel's
-    # own time and clock, against what a stream of independent FMAs reaches
-    n_inst = VALU_PER_WAVE_SAMPLE.get((args.algorithm, interp))
-    if n_inst and clock_mhz > 0 and samples > 0 and march_ms_avg > 0:
-        simds = 4 * 256
-        cyc = march_ms_avg * 1e-3 * clock_mhz * 1e6 * simds / (samples / 64.0 * n_inst)
-        roofline["valu_issue"] = {"insts_per_wave_sample": n_inst, "cycles_per_inst": round(cyc, 3),
-                                  "practical_cycles_per_inst": VALU_PRACTICAL_CYCLES_PER_INST,
-                                  "frac": round(VALU_PRACTICAL_CYCLES_PER_INST / cyc, 4),
-                                  "what": "instruction count from SQ_INSTS_VALU (profiles/), time and clock measured in this run"}
+                        "traffic_gbs": None, "frac": None, "algorithmic_bytes_vs_hbm_frac": round(texel_gbs / HBM_PEAK_GBS, 2)},
+                "note": "bound: instruction issue under the board's power cap.  achieved = VALU wave-instructions issued per second "
+                        "(SQ_INSTS_VALU measured in this run / kernel time), peak = what the chip's 1024 SIMDs issue at the clock the march "
+                        "measured for itself and the 2.17 cycles per instruction of independent FMAs; board_power says how close the "
+                        "kernel runs to the cap that sets that clock.  SURVEY 8d's algorithmic bytes are texel bytes served from LDS and "
+                        "lane registers: texel_rate_vs_lds prices them against the LDS read roof, lds_pipe counts the bytes that "
+                        "really pass the LDS pipe; HBM sees the ray state and the touched texels only (hbm.traffic, measured)"}
     out = None
     if rank == 0:
         roofline["hbm"]["copy_measured_gbs"] = round(lib.measure_copy_gbs(), 1)       # float4 streaming copy, read + write
@@ -550,15 +606,43 @@ def main():
         if args.cpu_sample_rays > 0 and world == 1:      # the CPU baseline is reported at N=1 only
             cpu = cpu_baseline(lambda n_sources: make_call(seed=1, n_sources=n_sources), vol_path, interp,
                                args.cpu_sample_rays, args.rays_per_source)
-        if world == 1 and not args.no_traffic and not os.environ.get("PHOTON_BENCH_CHILD"):
-            traffic, detail = measure_hbm_traffic(args, "march_kernel")
+        child = bool(os.environ.get("PHOTON_BENCH_CHILD"))
+        if world == 1 and not args.no_traffic and not child:
+            traffic, insts, detail = measure_counters(args, "march_kernel")
             roofline["traffic"] = traffic
             roofline["hbm"].update(detail)
             roofline["hbm"]["traffic"] = traffic
-            if traffic and march_ms_avg > 0:
-                gbs = traffic / (march_ms_avg * 1e-3) * 1e-9
+            if traffic and kernel_s > 0:
+                gbs = traffic / kernel_s * 1e-9
                 roofline["hbm"]["traffic_gbs"] = round(gbs, 1)
                 roofline["hbm"]["frac"] = round(gbs / HBM_PEAK_GBS, 4)
+            if insts and clock_mhz > 0 and wave_samples > 0 and kernel_s > 0:
+                # instruction counts of ONE launch of this very library and workload (the child runs the same command line),
+                # time and clock of the timed loop above
+                n_valu, n_lds, n_salu = insts["SQ_INSTS_VALU"], insts["SQ_INSTS_LDS"], insts["SQ_INSTS_SALU"]
+                cyc = kernel_s * clock_mhz * 1e6 * SIMDS / n_valu
+                issue_peak = SIMDS * clock_mhz * 1e6 / VALU_PRACTICAL_CYCLES_PER_INST * 1e-9
+                roofline["achieved"] = round(n_valu / kernel_s * 1e-9, 1)
+                roofline["peak"] = round(issue_peak, 1)
+                roofline["frac"] = round(roofline["achieved"] / issue_peak, 4)
+                roofline["valu_issue"] = {"valu_per_wave_sample": round(n_valu / wave_samples, 1), "salu_per_wave_sample": round(n_salu / wave_samples, 1),
+                                          "lds_per_wave_sample": round(n_lds / wave_samples, 2), "SQ_INSTS_VALU": n_valu,
+                                          "cycles_per_inst": round(cyc, 3), "practical_cycles_per_inst": VALU_PRACTICAL_CYCLES_PER_INST,
+                                          "frac": round(VALU_PRACTICAL_CYCLES_PER_INST / cyc, 4),
+                                          "what": "SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS measured in this run (rocprofv3 --pmc child pass), "
+                                                  "kernel time and clock from the timed loop"}
+                lds_gbs = n_lds * 1024.0 / kernel_s * 1e-9            # a wave-wide ds_read_b128 / ds_write_b128 moves 64 x 16 B
+                roofline["lds_pipe"] = {"achieved": round(lds_gbs, 1), "unit": "GB/s", "frac": round(lds_gbs / LDS_PEAK_GBS, 4),
+                                        "frac_at_clock": round(lds_gbs / peak_at_clock, 4) if peak_at_clock else None,
+                                        "what": "bytes that really pass the LDS pipe: SQ_INSTS_LDS x 1 KiB per wave instruction / kernel time"}
+        if roofline["achieved"] is None:
+            # no counter pass in this run (N > 1, --no-traffic, a child run): the top level falls back to SURVEY 8d's texel rate
+            t = roofline["texel_rate_vs_lds"]
+            roofline.update({"bound": "lds (texel delivery; instruction counts not measured in this run)", "achieved": t["achieved"],
+                             "peak": t["peak"], "unit": "GB/s", "frac": t["frac"]})
+        others = None
+        if world == 1 and not child and not args.no_other_configs:
+            others = gpu_other_configs(lib, torch, workdir, args.c4)
         desc = (f"C3: BOS, {total_rays} rays ({job_sources} sources x {args.rays_per_source}"
                 f"{' per GPU' if not strong and world > 1 else ''}), {args.volume}^3 volume, "
                 f"{'RK4' if args.algorithm == 2 else 'Euler'}, {args.interp} sampler, "
@@ -573,7 +657,7 @@ def main():
                                        if strong else f"{world} rank(s), one per GPU, one scene each; ")
                                       + "private images, one RCCL sum-reduce onto rank 0 per step",
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1) if not args.rehearse else 0},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "gpu_other_configs": others,
             "volume_build_s": round(volume_build_s, 3), "rays_on_sensor": on_sensor_total,
             # `value` counts every ray of the job; rays dropped before the march as doomed (none for BOS cones) are in
             # rays_total but not in rays_marched
@@ -581,6 +665,7 @@ def main():
         }
         if world == 1 and not os.environ.get("PHOTON_BENCH_CHILD"):
             out["abi_call"] = time_abi_call(lib, call, interp)
+        do_check = args.check or (world > 1 and not child)      # every multi-GPU line carries its own parity check
         if args.rehearse:
             out["rehearsal"] = (f"{world} ranks SHARING one GPU, gloo reduce of host copies: exercises this script's N > 1 logic; "
                                 "NOT a multi-GPU measurement")
@@ -593,8 +678,21 @@ def main():
                 got = image.cpu().numpy().reshape(H, W).astype(np.float64)
                 out["check"] = {"rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "sources": job_sources,
                                 "what": "reduced image of all ranks vs the oracle's render of the whole job"}
-        elif args.check:
+        elif do_check:
             out["check"] = check_against_oracle(lib, make_call, vol_path, interp)
+            if world > 1:
+                # the REDUCED image of the last timed step (all ranks' shards, summed by RCCL onto this rank) against the same
+                # job rendered by this GPU alone: sharding, shard-only uploads and the reduce, end to end
+                single = torch.zeros_like(image)
+                for seed in ([1] if strong else [1 + r for r in range(world)]):
+                    whole = lib.scene_create(make_call(seed=seed))
+                    whole.trace(single.data_ptr(), volume, args.algorithm, stream=stream)      # accumulates
+                    torch.cuda.synchronize()
+                    whole.free()
+                diff = (image.double() - single.double()).norm() / single.double().norm()
+                out["check"]["sharded_vs_single_gpu_rel_l2"] = float(diff.item())
+                out["check"]["what"] = ("rel_l2: 40 sources through start_ray_tracing vs the CPU oracle; sharded_vs_single_gpu_rel_l2: the "
+                                        "image all ranks reduced onto rank 0 vs the whole job rendered by rank 0's GPU alone")
         print(json.dumps(out), flush=True)
     scene.free()
     volume.free()

@@ -265,10 +265,25 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
  * start_ray_tracing reads it from PHOTON_ELEMENT_TRAIN=reference|sequential. */
 int photon_scene_set_element_train(photon_scene_t *scene, int mode);
 
-/* The partition of a march launch over its 64 work queues (host restatement of the kernel's own function, for tests):
- * index of the k-th 64-ray group handed out by sub-queue `sub` (0..7) of XCD `xcd` (0..7).  A launch of G groups is
- * served when every queue has handed out all its groups below G; each group belongs to exactly one queue. */
+/* The partition of a march launch over its work queues (host restatement of the kernel's own functions, for tests).
+ * photon_march_queue_count() queues -- 8 XCDs x (count / 8) sub-queues, 32 in the shipped build; queue (xcd, sub) owns the
+ * 8K-ray chunks c with c % count == sub * 8 + xcd.  photon_march_queue_group: index of the k-th 64-ray group that queue
+ * hands out (grows with k); photon_march_queue_size: how many of a launch's n_groups groups it owns.  Every group of a
+ * launch belongs to exactly one queue.  An xcd >= 8 or a sub >= count / 8 returns UINT_MAX.
+ * A launch whose marches are cut into S segments (photon_scene_set_march_segments) hands out size * S items per queue,
+ * segment-major: item k is segment k / size of the queue's (k % size)-th group. */
+unsigned photon_march_queue_count(void);
 unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub);
+unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub);
+
+/* Segments per march (speed only; the image does not depend on it, nor do the marched rays: tests).  A 64-ray group marches
+ * for ~2 ms and a launch ends when its last group does, so the chip idles for most of a group time at the end of every
+ * launch; a launch of several chip fills therefore cuts every march into `segments` pieces of equal trip count, handed out
+ * breadth-first, and a ray's loop state travels with it from piece to piece.  -1 (default) = the library's choice
+ * (PHOTON_MARCH_SEGMENTS, 8, in launches of at least 1.25 chip fills), 1 = whole marches, 2..64 = that many in every
+ * launch, whatever its size (tests).  Launches that write intermediate ray dumps or use gradient noise are never segmented.
+ * start_ray_tracing reads PHOTON_MARCH_SEGMENTS=<n> (the library's choice) or force:<n> (every launch). */
+int photon_scene_set_march_segments(photon_scene_t *scene, int segments);
 
 /* A scene that holds only a SLICE of a job's source list (one rank of a multi-GPU job uploads just its shard): the
  * index, in the job's list, of this scene's first source.  Only the noise hooks read it -- their generator is keyed by the

@@ -569,6 +569,21 @@ __device__ __forceinline__ void record_intermediate(const InterDump &d, int loop
     }
 }
 
+// SEGMENTED MARCH (round 4).  A launch may cut every ray's march into segments of at most `max_trips` trips of the loops
+// below, handled by different waves at different times (photon_core.hip, march_kernel): what a ray carries from one
+// segment to the next, besides its position and direction, is exactly the loops' per-lane state -- the completed
+// iterations (loop_ctr; "first" = none yet), the `continue` spins, and for the trilinear branches the last value sampled
+// (val_prev, the repair of .h:1056-1065).  What is wave-level -- the parked tile, the trip counter -- starts afresh, and
+// none of it enters a ray's arithmetic: a segmented march returns the bits of an unsegmented one.
+struct MarchResume {
+    int loop_ctr, spins;            // per lane
+    f4 val_prev;                    // per lane; the trilinear branches only
+    unsigned max_trips;             // wave-uniform: trips this call may run (~0u: until every ray has left)
+    unsigned trips_base;            // wave-uniform: an upper bound of the trips earlier segments ran (the kLoopMax cap)
+    bool fresh;                     // wave-uniform: first segment (the rays enter the volume here)
+};
+__device__ __forceinline__ MarchResume resume_fresh() { return MarchResume{0, 0, f4{0, 0, 0, 0}, ~0u, 0u, true}; }
+
 // Wave-synchronous RK4 (reference: trace_rays_through_density_gradients.h:952-1291).  All 64
 // lanes call it; active_lane = this lane carries a ray that is inside (or entering) the volume.  One
 // trip of the loop is one RK4 iteration: Sharma's three samples A, B, C in straight-line code with
@@ -580,21 +595,23 @@ __device__ __forceinline__ void record_intermediate(const InterDump &d, int loop
 // Shape of the code (round 3): the stage algebra runs UNPREDICATED on every lane -- a lane that does not take part
 // computes garbage nobody reads -- and the predicates (active, go, spin, first) are wave masks; only the commit of a
 // finished iteration and the rare paths are predicated.
+// Returns the mask of the lanes still marching when the call ran out of trips (0 unless rs.max_trips cut it short).
 template <int INTERP, bool SAVE, bool QUANT, class CNT>
-__device__ __forceinline__ void rk4_coop(bool active_lane, f3 &rpos, f3 &rdir, const VolumeDev &v,
-                                         const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
-                                         const InterDump &idump) {
+__device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpos, f3 &rdir, const VolumeDev &v,
+                                                       const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
+                                                       const InterDump &idump, MarchResume &rs) {
     const MarchU u = make_march_consts(v, scale);
-    int loop_ctr = 0, spins = 0;
-    unsigned trips = 0;                                         // wave-uniform; no lane's loop_ctr exceeds it
+    int loop_ctr = rs.loop_ctr, spins = rs.spins;
+    unsigned trips = rs.trips_base;                             // wave-uniform; no lane's loop_ctr exceeds it
+    const unsigned trips_end = rs.max_trips == ~0u ? ~0u : trips + rs.max_trips;
     Parked parked = parked_none();
     // val_prev: the last value a lane sampled (n-1 form), for the linear branch's repair.  Updated unpredicated; the
     // only live lanes that sit samples out are spinning ones, which have not sampled yet (a ray spins only on its first
     // iteration, see inside_mask) -- theirs is put back to its initial zeros at the end of such a trip.
-    f4 val_prev = f4{0, 0, 0, 0};
+    f4 val_prev = rs.val_prev;
     unsigned long long active = ballot(active_lane);
-    unsigned long long first = active;                          // lanes with loop_ctr == 0
-    while (active != 0) {                                       // wave-uniform loop
+    unsigned long long first = active & ballot(loop_ctr == 0);  // lanes with loop_ctr == 0
+    while (active != 0 && trips < trips_end) {                  // wave-uniform loop
         // ---------------- sample A at R_n (= rpos) ----------------
         f3 lookup = lookup_index_u(rpos, u);
         const unsigned long long in_a = inside_mask(rpos, u);
@@ -658,6 +675,9 @@ __device__ __forceinline__ void rk4_coop(bool active_lane, f3 &rpos, f3 &rdir, c
         count_iterations(mc, go);
         if (INTERP == 1 && spin != 0) { if (lane_of(spin)) val_prev = f4{0, 0, 0, 0}; }
     }
+    rs.loop_ctr = loop_ctr; rs.spins = spins;
+    if (INTERP == 1) rs.val_prev = val_prev;
+    return active;
 }
 
 // Wave-synchronous Euler integrator (reference: .h:743-950): one cooperative sample per trip.  Per-ray operation
@@ -667,17 +687,18 @@ __device__ __forceinline__ void rk4_coop(bool active_lane, f3 &rpos, f3 &rdir, c
 struct GradNoise { int on; float std; unsigned long long seed, ray_id; };
 
 template <int INTERP, bool SAVE, bool NOISE, bool QUANT, class CNT>
-__device__ __forceinline__ void euler_coop(bool active_lane, f3 &rpos, f3 &rdir, const VolumeDev &v,
-                                           const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
-                                           const GradNoise &gn, const InterDump &idump) {
+__device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &rpos, f3 &rdir, const VolumeDev &v,
+                                                         const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
+                                                         const GradNoise &gn, const InterDump &idump, MarchResume &rs) {
     const MarchU u = make_march_consts(v, scale);
-    int loop_ctr = 0, spins = 0;
-    unsigned trips = 0;
+    int loop_ctr = rs.loop_ctr, spins = rs.spins;
+    unsigned trips = rs.trips_base;
+    const unsigned trips_end = rs.max_trips == ~0u ? ~0u : trips + rs.max_trips;
     Parked parked = parked_none();
-    f4 val_prev = f4{0, 0, 0, 0};
+    f4 val_prev = rs.val_prev;
     unsigned long long active = ballot(active_lane);
-    unsigned long long first = active;
-    while (active != 0) {
+    unsigned long long first = active & ballot(loop_ctr == 0);
+    while (active != 0 && trips < trips_end) {
         const f3 lookup = lookup_index_u(rpos, u);
         const unsigned long long in_a = inside_mask(rpos, u);
         unsigned long long not_over = ~0ull;
@@ -729,18 +750,23 @@ __device__ __forceinline__ void euler_coop(bool active_lane, f3 &rpos, f3 &rdir,
         loop_ctr += lane_of(go) ? 1 : 0;
         count_iterations(mc, go);
     }
+    rs.loop_ctr = loop_ctr; rs.spins = spins;
+    if (INTERP == 1) rs.val_prev = val_prev;
+    return active;
 }
 
 // trace_rays_through_density_gradients (.h:1455-1544), wave-synchronous.  has_ray = this lane
 // carries a ray at all (tail lanes of the last workgroup do not).
+// rs: where the rays stand (resume_fresh(): at their start, the whole march in one call); for a later segment has_ray =
+// this lane's ray was still marching when the previous one ended.  Returns the mask of the lanes still marching.
 template <int ALGO, int INTERP, bool SAVE, bool NOISE, bool QUANT, class CNT>
-__device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &dir_io, const VolumeDev &v,
-                                                  const f4 *__restrict__ tex, f4 *blk, CNT &mc,
-                                                  const GradNoise &gn, const InterDump &idump) {
+__device__ __forceinline__ unsigned long long trace_volume_coop(bool has_ray, f3 &pos_io, f3 &dir_io, const VolumeDev &v,
+                                                                const f4 *__restrict__ tex, f4 *blk, CNT &mc,
+                                                                const GradNoise &gn, const InterDump &idump, MarchResume &rs) {
     const f3 mn = v.min_bound, mx = v.max_bound;
     const f3 scale = mk3(1.0f / (mx.x - mn.x), 1.0f / (mx.y - mn.y), 1.0f / (mx.z - mn.z));
     bool active = has_ray;
-    if (has_ray) {
+    if (has_ray && rs.fresh) {
         f3 pos = pos_io;
         const f3 dir = dir_io;
         if (pos.x <= mn.x || pos.y <= mn.y || pos.z <= mn.z || pos.x >= mx.x || pos.y >= mx.y || pos.z >= mx.z) {
@@ -748,8 +774,8 @@ __device__ __forceinline__ void trace_volume_coop(bool has_ray, f3 &pos_io, f3 &
         }
         if (active) pos_io = pos;
     }
-    if (ALGO == 1) euler_coop<INTERP, SAVE, NOISE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump);
-    else rk4_coop<INTERP, SAVE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump);
+    if (ALGO == 1) return euler_coop<INTERP, SAVE, NOISE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump, rs);
+    return rk4_coop<INTERP, SAVE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump, rs);
 }
 
 }  // namespace photon

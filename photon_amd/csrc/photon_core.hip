@@ -97,6 +97,12 @@ static int guarded(const char *what, F &&body) {
 struct RayStateDev {                // SoA ray state between the march and the sensor stage
     float *px, *py, *pz, *dx, *dy, *dz;
     double *radiance;
+    // what a ray carries between the segments of a segmented march (device_volume_coop.hpp, MarchResume), per ray:
+    unsigned *ctr;                  // bit 31: still marching; bits 0-30: completed iterations
+    unsigned *spins;
+    float *vprev;                   // [4][rays]: the last value sampled (trilinear branches)
+    unsigned *seg_flag;             // per 64-ray group: (launch epoch << 8) | segments completed (0xff: every ray has left)
+    unsigned stride;                // rays the arrays were allocated for (distance between the four planes of vprev)
 };
 
 struct DumpDev {                    // ray dumps (save_lightrays), indexed by chunk-global ray id
@@ -342,10 +348,11 @@ __global__ __launch_bounds__(256) void march_rays_kernel(VolumeDev v, const f4 *
     MarchCount mc{0, 0};
     const GradNoise no_noise{0, 0.f, 0ull, 0ull};
     const InterDump no_dump{nullptr, nullptr, 0, 0, 0u};
+    MarchResume rs = resume_fresh();
     if (INTERP == 1 && v.weight_scale > 0.f)                    // kernel-uniform: texture-unit weights
-        trace_volume_coop<ALGO, INTERP, false, false, true, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
+        trace_volume_coop<ALGO, INTERP, false, false, true, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump, rs);
     else
-        trace_volume_coop<ALGO, INTERP, false, false, false, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump);
+        trace_volume_coop<ALGO, INTERP, false, false, false, MarchCount>(has_ray, p, d, v, tex, tiles[threadIdx.x >> 6], mc, no_noise, no_dump, rs);
     if (has_ray) {
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
         dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
@@ -435,6 +442,9 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 #ifndef PHOTON_MARCH_PERSISTENT
 #define PHOTON_MARCH_PERSISTENT 1
 #endif
+#ifndef PHOTON_MARCH_SEGMENTS
+#define PHOTON_MARCH_SEGMENTS 8         // segments a ray's march is cut into in launches of several chip fills (march_group)
+#endif
 constexpr unsigned kQueueStride = 16;                           // u32 per queue counter: one 64-byte line each
 #ifndef PHOTON_SUBQUEUES
 #define PHOTON_SUBQUEUES 4              // work queues per XCD (a power of two, <= 8); measured 1 / 2 / 4 / 8, see march_kernel
@@ -463,6 +473,10 @@ struct MarchArgs {
     InterDump idump;
     unsigned *queue;
     unsigned long long *profile;        // this launch's wave-timing slots (photon_scene_set_march_profile), or nullptr
+    unsigned segments;                  // segments every ray's march is cut into (1: whole marches, the state arrays below unused)
+    unsigned seg_trips;                 // trips of the march loop per segment (the last segment runs until every ray has left)
+    unsigned epoch;                     // tag of this launch in RayStateDev::seg_flag
+    unsigned *error;                    // waves that gave a segment up (zero unless the hand-off between segments is broken)
 };
 typedef const __attribute__((address_space(4))) MarchArgs *MarchArgsPtr;
 template <class T>
@@ -502,31 +516,92 @@ struct WaveTotals {
     unsigned long long clk_sum = 0, real_sum = 0;               // shader-clock / 100 MHz ticks spent in groups
 };
 
-// One 64-ray group: load the state, march, store it back.  Must be called by all 64 lanes of the wave.
+// Groups of a launch of n_groups that belong to queue (xcd, sub): its items are k = 0 .. that many - 1 (march_queue_group).
+__host__ __device__ inline unsigned march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub) {
+    constexpr unsigned Q = 8u * kSubQueues;                     // chunk c belongs to queue c % Q = sub * 8 + xcd
+    const unsigned q = sub * 8u + xcd, full = n_groups / kGroupsPerChunk, rem = n_groups % kGroupsPerChunk;
+    return (full / Q + (full % Q > q ? 1u : 0u)) * kGroupsPerChunk + (full % Q == q ? rem : 0u);
+}
+
+// Agent-scope relaxed accesses (global_load / global_store ... sc1): the loads bypass this CU's L1, the stores write
+// through the XCD's L2 -- how the ray state travels from the wave that marched one segment of a group to the wave, on any
+// CU of any XCD, that marches the next (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload, the storing wave's
+// own vmcnt(0), an sc1 flag; the reader polls the flag with an sc1 load, then an agent acquire, then sc1 loads).
+template <class T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr int kSegPollMax = 1 << 20;                            // polls (~2 us each) before a wave gives a segment up: the exit every wave reaches
+constexpr unsigned kSegDone = 0xffu;                            // seg_flag: every ray of the group has left the volume
+
+// One item of the launch: segment `seg` of 64-ray group `group` -- load the state, march, store it back.  Must be called
+// by all 64 lanes of the wave.  With MarchArgs::segments == 1 (seg = 0) this is the whole march of the group.
+//
+// SEGMENTS (round 4).  A group marches for ~1.9 ms whatever the launch, and a launch ends when its LAST group does: the
+// waves finish one by one over the final ~0.8 group times while the rest of the chip idles (measured with the wave-timing
+// profile: span - mean end; 1.6 ms of a 9.5 ms launch of one GPU's eighth of the headline job, the same 1.6 ms of the full
+// job's 60).  Cutting every march into S segments handed out breadth-first (all first segments, then all second ones, ...)
+// makes the quantum S times smaller and the drain with it; the state a ray carries between segments is the loops' own
+// (MarchResume), so the bits do not change.  A segment's wave may have to wait for the wave still marching the previous
+// one (only when a launch has fewer groups than the chip holds waves: the host does not segment those): it polls the
+// group's flag, bounded -- a wave that gives up counts itself in MarchArgs::error and leaves (march_error_check).
 template <int ALGO, int INTERP, bool SAVE, bool NOISE>
-__device__ __forceinline__ void march_group(unsigned group, unsigned n_rays, f4 *tile, WaveTotals &tot) {
+__device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsigned n_rays, f4 *tile, WaveTotals &tot) {
     unsigned long long clk0, real0, clk1, real1;
     clock_stamp(clk0, real0);
+    const unsigned lane = threadIdx.x & 63u;
     if (tot.groups++ == 0) {                                    // wave-uniform: this wave's first group
         unsigned long long *pf = profile_slot();
-        if (pf && (threadIdx.x & 63u) == 0) {
+        if (pf && lane == 0) {
             atomicMax(&pf[PF_START_NEGMIN], ~real0); atomicAdd(&pf[PF_START_SUM], real0); atomicMax(&pf[PF_START_MAX], real0);
         }
     }
-    const unsigned r = group * 64u + (threadIdx.x & 63u);
+    const unsigned r = group * 64u + lane;
     const bool has_ray = r < n_rays;
     f3 p = mk3(0, 0, 0), d = mk3(0, 0, -1);
     bool marching = has_ray;
     MarchArgsPtr a = march_args();
+    MarchResume rs = resume_fresh();
     {
+        const bool fresh = seg == 0;                            // wave-uniform
         const RayStateDev st = load_arg(&a->st);
-        if (has_ray) {
-            p = mk3(st.px[r], st.py[r], st.pz[r]);
-            d = mk3(st.dx[r], st.dy[r], st.dz[r]);
-            marching = !isnan3(p);                              // rays marked dead by raygen_kernel stay out of the march
+        if (!fresh) {
+            // the previous segment of this group: handed out before this one, to a wave that is running -- normally long done
+            const unsigned want = a->epoch;
+            unsigned flag = 0;
+            int polls = 0;
+            while (true) {
+                unsigned f = 0;
+                if (lane == 0) f = ld_agent(&st.seg_flag[group]);
+                flag = (unsigned)__builtin_amdgcn_readfirstlane((int)f);
+                if ((flag >> 8) == want && (flag & 0xffu) >= seg) break;
+                if (++polls > kSegPollMax) {                    // never seen; an exit every wave reaches
+                    if (lane == 0) atomicAdd(a->error, 1u);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if ((flag & 0xffu) == kSegDone) return;             // wave-uniform: no ray of this group is still in the volume
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
+        if (has_ray) {
+            p = mk3(ld_agent(&st.px[r]), ld_agent(&st.py[r]), ld_agent(&st.pz[r]));
+            d = mk3(ld_agent(&st.dx[r]), ld_agent(&st.dy[r]), ld_agent(&st.dz[r]));
+            if (fresh) {
+                marching = !isnan3(p);                          // rays marked dead by raygen_kernel stay out of the march
+            } else {
+                const unsigned c = ld_agent(&st.ctr[r]);
+                marching = (c >> 31) != 0u;
+                rs.loop_ctr = (int)(c & 0x7fffffffu);
+                rs.spins = (int)ld_agent(&st.spins[r]);
+                if (INTERP == 1) {
+                    const size_t n = st.stride;
+                    rs.val_prev = f4{ld_agent(&st.vprev[r]), ld_agent(&st.vprev[n + r]), ld_agent(&st.vprev[2 * n + r]), ld_agent(&st.vprev[3 * n + r])};
+                }
+            }
+        }
+        if (!fresh) { rs.fresh = false; rs.trips_base = seg * a->seg_trips; }
+        if (seg + 1u < a->segments) rs.max_trips = a->seg_trips;
+        tot.n_marched += fresh ? (unsigned)__popcll(ballot(marching)) : 0u;
     }
-    const unsigned group_marched = (unsigned)__popcll(ballot(marching));
     const VolumeDev vol = load_arg(&a->vol);
     const f4 *tex = a->tex;
     GradNoise gn{0, 0.f, 0ull, 0ull};
@@ -534,19 +609,41 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned n_rays, f4 
     InterDump idump{nullptr, nullptr, 0, 0, 0u};
     if (SAVE) idump = load_arg(&a->idump);
     idump.ray = r;                                              // chunk-global ray id, like the final dumps
+    unsigned long long still;                                   // lanes whose rays are still in the volume when the segment ends
     if (INTERP == 1 && vol.weight_scale > 0.f)                  // kernel-uniform: the texture unit's 8-bit weights (the default) / exact f32
-        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tile, tot.mc, gn, idump);   // all 64 lanes
+        still = trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tile, tot.mc, gn, idump, rs);   // all 64 lanes
     else
-        trace_volume_coop<ALGO, INTERP, SAVE, NOISE, false, WaveCount>(marching, p, d, vol, tex, tile, tot.mc, gn, idump);
+        still = trace_volume_coop<ALGO, INTERP, SAVE, NOISE, false, WaveCount>(marching, p, d, vol, tex, tile, tot.mc, gn, idump, rs);
     {
-        const RayStateDev st = load_arg(&march_args()->st);     // loaded again: not carried through the march in SGPRs
-        if (marching) {
-            st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
-            st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+        MarchArgsPtr b = march_args();
+        const RayStateDev st = load_arg(&b->st);                // loaded again: not carried through the march in SGPRs
+        const bool fresh = seg == 0, last = seg + 1u >= b->segments;      // likewise
+        const unsigned group = (unsigned)__builtin_amdgcn_readfirstlane((int)r) >> 6;
+        if (last) {
+            if (marching) {
+                st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
+                st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
+            }
+        } else {
+            if (marching) {                                     // where the rays that marched this segment stand now
+                st_agent(&st.px[r], p.x); st_agent(&st.py[r], p.y); st_agent(&st.pz[r], p.z);
+                st_agent(&st.dx[r], d.x); st_agent(&st.dy[r], d.y); st_agent(&st.dz[r], d.z);
+            }
+            if (fresh ? has_ray : marching) {
+                st_agent(&st.ctr[r], (lane_of(still) ? 0x80000000u : 0u) | (unsigned)rs.loop_ctr);
+                st_agent(&st.spins[r], (unsigned)rs.spins);
+                if (INTERP == 1) {
+                    const size_t n = st.stride;
+                    st_agent(&st.vprev[r], rs.val_prev.x); st_agent(&st.vprev[n + r], rs.val_prev.y);
+                    st_agent(&st.vprev[2 * n + r], rs.val_prev.z); st_agent(&st.vprev[3 * n + r], rs.val_prev.w);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's stores have reached memory ...
+            if (lane == 0) st_agent(&st.seg_flag[group], (b->epoch << 8) | (still != 0 ? seg + 1u : kSegDone));      // ... before its flag
         }
     }
     clock_stamp(clk1, real1);
-    if (group_marched) { tot.n_marched += group_marched; tot.clk_sum += clk1 - clk0; tot.real_sum += real1 - real0; }
+    tot.clk_sum += clk1 - clk0; tot.real_sum += real1 - real0;
 }
 
 template <int ALGO, int INTERP, bool SAVE, bool NOISE>
@@ -573,6 +670,7 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
     // Taking several groups per access instead of adding queues was tried and dropped: wherever trivial and real groups
     // mix (doomed lens samples of a PIV launch) a wave ends up holding dozens of real groups while the chip drains (C5
     // quarter 38.6 -> 92 ms).
+    // A queue of Gq groups hands out Gq x S items, segment-major: item k = segment k / Gq of its (k % Gq)-th group.
     const unsigned home_x = blockIdx.x & 7u, home_s = (blockIdx.x >> 3) & (kSubQueues - 1u);
     for (unsigned step = 0; step < kSubQueues + 7u; step++) {
         const unsigned x = step < kSubQueues ? home_x : ((home_x + step - (kSubQueues - 1u)) & 7u);
@@ -582,16 +680,18 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
             if (lane == 0) k = atomicAdd(&march_args()->queue[(sub * 8u + x) * kQueueStride], 1u);
             k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             const unsigned n_rays = march_args()->n_rays;
-            const unsigned group = march_queue_group(k, x, sub);
-            if (group >= (n_rays + 63u) / 64u) break;           // groups grow with k: this queue is served
-            march_group<ALGO, INTERP, SAVE, NOISE>(group, n_rays, tile, tot);
+            const unsigned gq = march_queue_size((n_rays + 63u) / 64u, x, sub);
+            const unsigned n_seg = march_args()->segments;
+            if (k >= gq * n_seg) break;                         // this queue is served (k < 2^26 / 64 * 255: no overflow)
+            const unsigned seg = n_seg > 1u ? k / gq : 0u;
+            march_group<ALGO, INTERP, SAVE, NOISE>(march_queue_group(k - seg * gq, x, sub), seg, n_rays, tile, tot);
         }
     }
 #else
     {                                                           // one-shot grid (A/B builds): one group per wave
         const unsigned n_rays = march_args()->n_rays;
         const unsigned group = xcd_remap(blockIdx.x, gridDim.x) * (PHOTON_MARCH_BLOCK / 64) + (threadIdx.x >> 6);
-        if (group < (n_rays + 63u) / 64u) march_group<ALGO, INTERP, SAVE, NOISE>(group, n_rays, tile, tot);
+        if (group < (n_rays + 63u) / 64u) march_group<ALGO, INTERP, SAVE, NOISE>(group, 0u, n_rays, tile, tot);
     }
 #endif
     if (tot.groups) {                                           // wave-uniform
@@ -606,8 +706,8 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
         unsigned long long *slot = counter_slot(march_args()->counters);
         if (tot.mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)tot.mc.iterations);
         if (tot.mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)tot.mc.samples);
-        if (tot.n_marched) {
-            atomicAdd(&slot[CNT_MARCHED], (unsigned long long)tot.n_marched);
+        if (tot.n_marched) atomicAdd(&slot[CNT_MARCHED], (unsigned long long)tot.n_marched);
+        if (tot.real_sum) {
             atomicAdd(&slot[CNT_CLK], tot.clk_sum);
             atomicAdd(&slot[CNT_REAL], tot.real_sum);
         }
@@ -862,6 +962,9 @@ struct photon_scene {
     unsigned long long *d_counters = nullptr;
     unsigned *d_queue = nullptr;        // the march's work queues: 64 counters (8 XCDs x 8 sub-queues), a cache line apart
     int num_cus = 256;                  // compute units of the scene's device (size of the persistent march grid)
+    unsigned *d_error = nullptr;        // march waves that gave a segment up (march_error_check)
+    unsigned march_epoch = 0;           // tag of the last segmented march launch in ws.seg_flag
+    int march_segments = -1;            // photon_scene_set_march_segments: -1 the library's choice, 1 whole marches, n segments
     unsigned long long *d_profile = nullptr;    // wave-timing slots of the march launches (photon_scene_set_march_profile), or nullptr
     unsigned prof_next = 0;             // march launches since the slots were last zeroed
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
@@ -882,6 +985,8 @@ struct photon_scene {
     unsigned long long perm_clock = 0;
     photon_sort_scratch sort_scratch;   // keys / indices / radix-sort temporaries, grown on demand (photon_sort.hip)
 };
+
+static void free_resume_state(photon_scene *s);
 
 template <typename T>
 static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
@@ -1288,9 +1393,11 @@ void photon_scene_free(photon_scene_t *s) {
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->ws.px) (void)hipFree(s->ws.px);
     if (s->ws.radiance) (void)hipFree(s->ws.radiance);
+    free_resume_state(s);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_profile) (void)hipFree(s->d_profile);
+    if (s->d_error) (void)hipFree(s->d_error);
     if (s->d_acc) (void)hipFree(s->d_acc);
     for (auto &p : s->perms) if (p.d_perm) (void)hipFree(p.d_perm);
     photon_sort_scratch_free(&s->sort_scratch);
@@ -1543,6 +1650,9 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     e = hipMalloc((void **)&s->d_queue, kQueues * kQueueStride * sizeof(unsigned));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    e = hipMalloc((void **)&s->d_error, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(s->d_error, 0, sizeof(unsigned));
+    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -1564,7 +1674,13 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
     return 0;
 }
 
-unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub) { return march_queue_group(k, xcd & 7u, sub & (kSubQueues - 1u)); }
+unsigned photon_march_queue_count(void) { return 8u * kSubQueues; }
+unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub) {
+    return xcd < 8u && sub < kSubQueues ? march_queue_group(k, xcd, sub) : ~0u;
+}
+unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub) {
+    return xcd < 8u && sub < kSubQueues ? march_queue_size(n_groups, xcd, sub) : ~0u;
+}
 
 int photon_scene_set_source_base(photon_scene_t *s, int64_t first_source) {
     if (!s || first_source < 0) return 1;
@@ -1595,10 +1711,17 @@ int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {
 // rays per launch: bounded so that 32-bit ray ids suffice and the state stays a few GB
 static const unsigned kMaxRaysPerLaunch = 1u << 26;
 
+static void free_resume_state(photon_scene *s) {
+    if (s->ws.ctr) { (void)hipFree(s->ws.ctr); s->ws.ctr = nullptr; }
+    if (s->ws.vprev) { (void)hipFree(s->ws.vprev); s->ws.vprev = nullptr; }
+    s->ws.spins = nullptr; s->ws.seg_flag = nullptr;
+}
+
 static int ensure_workspace(photon_scene *s, size_t rays) {
     if (s->ws_rays >= rays) return 0;
     if (s->ws.px) { (void)hipFree(s->ws.px); s->ws.px = nullptr; }
     if (s->ws.radiance) { (void)hipFree(s->ws.radiance); s->ws.radiance = nullptr; }
+    free_resume_state(s);
     s->ws_rays = 0;
     float *f = nullptr;
     PH_CHECK(hipMalloc((void **)&f, rays * 6 * sizeof(float)));
@@ -1606,6 +1729,27 @@ static int ensure_workspace(photon_scene *s, size_t rays) {
     s->ws.dx = f + 3 * rays; s->ws.dy = f + 4 * rays; s->ws.dz = f + 5 * rays;
     PH_CHECK(hipMalloc((void **)&s->ws.radiance, rays * sizeof(double)));
     s->ws_rays = rays;
+    s->ws.stride = (unsigned)rays;
+    return 0;
+}
+
+// What a segmented march keeps per ray between segments (MarchResume) and the per-group flags; allocated with the first
+// segmented launch of a workspace size.  The flags carry the launch's epoch, so they are zeroed once, here (and when the
+// 24-bit epoch wraps), not per launch.
+static int ensure_resume_state(photon_scene *s, bool linear, hipStream_t stream) {
+    const size_t rays = s->ws_rays, groups = (rays + 63) / 64;
+    if (!s->ws.ctr) {
+        unsigned *u = nullptr;
+        PH_CHECK(hipMalloc((void **)&u, (2 * rays + groups) * sizeof(unsigned)));
+        s->ws.ctr = u; s->ws.spins = u + rays; s->ws.seg_flag = u + 2 * rays;
+        PH_CHECK(hipMemsetAsync(s->ws.seg_flag, 0, groups * sizeof(unsigned), stream));
+        s->march_epoch = 0;
+    }
+    if (linear && !s->ws.vprev) PH_CHECK(hipMalloc((void **)&s->ws.vprev, 4 * rays * sizeof(float)));
+    if (++s->march_epoch >= (1u << 24)) {
+        PH_CHECK(hipMemsetAsync(s->ws.seg_flag, 0, groups * sizeof(unsigned), stream));
+        s->march_epoch = 1;
+    }
     return 0;
 }
 
@@ -1714,6 +1858,15 @@ static float doom_margin(const photon_scene *s, const photon_volume *vol, int al
     return (float)margin;
 }
 
+// Segments per march of a launch large enough to be segmented: PHOTON_MARCH_SEGMENTS=<n> (1 = whole marches), or
+// PHOTON_MARCH_SEGMENTS=force:<n> to segment launches of any size (tests of the hand-off between segments).
+static int march_segments_default(bool *forced) {
+    const char *e = getenv("PHOTON_MARCH_SEGMENTS");            // read per launch: tests switch it between calls
+    if (e && !strncmp(e, "force:", 6)) { *forced = true; e += 6; }
+    const int v = (e && atoi(e) > 0) ? atoi(e) : PHOTON_MARCH_SEGMENTS;
+    return v > 64 ? 64 : v;
+}
+
 static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
                         long long src_end, DumpDev dump, hipStream_t stream, hipEvent_t ev_march_begin, hipEvent_t ev_march_end) {
     double *d_image = s->d_acc;
@@ -1756,7 +1909,27 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         unsigned long long *profile = nullptr;                  // wave timing of this launch, while there are free slots
         if (s->d_profile && s->prof_next < kProfileLaunches && (algorithm == 1 || algorithm == 2))
             profile = s->d_profile + (size_t)(s->prof_next++) * kProfileSub * PF_N;
-        const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue, profile};
+        // Segments: only where the launch is several times what the chip holds at once (a segment's wave then finds the
+        // previous segment of its group long done) and nothing indexes a ray's iterations (dumps, gradient noise).
+        unsigned segments = 1, seg_trips = 0;
+        if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2) && !save && !s->dev.noise.add_ngrad) {
+            const unsigned groups = (n + 63u) / 64u;
+            // resident march waves: five per SIMD (the launch bound of the march kernels)
+            const unsigned slots = (unsigned)s->num_cus * 4u * PHOTON_MARCH_WAVES;
+            bool forced = s->march_segments > 1;                // an explicit count segments launches of any size (tests)
+            const int want = s->march_segments >= 0 ? s->march_segments : march_segments_default(&forced);
+            if (want > 1 && (forced || groups >= slots + slots / 4)) {
+                // equal trip counts, and (unless the count is forced) at least 16 trips per segment: the state round trip and
+                // the refetch of the parked tile are then below a per cent of the segment (a 48^3 volume: 3 segments, not 8)
+                const unsigned depth = (unsigned)std::max(vol->dev.nx, std::max(vol->dev.ny, vol->dev.nz));
+                segments = (unsigned)std::min(want, 64);
+                if (!forced) segments = std::max(1u, std::min(segments, depth / 16u));
+                seg_trips = std::max(4u, (depth + segments - 1) / segments);
+                if (segments > 1) { rc = ensure_resume_state(s, interp == 1, stream); if (rc) return rc; }
+            }
+        }
+        const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue, profile,
+                              segments, seg_trips, s->march_epoch, s->d_error};
 #define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), mgrid, mblock, 0, stream, margs)
         if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
@@ -1847,6 +2020,12 @@ static int profile_reset(photon_scene *s, hipStream_t stream) {
     return 0;
 }
 
+extern "C" int photon_scene_set_march_segments(photon_scene_t *scene, int segments) {
+    if (!scene || segments < -1 || segments == 0 || segments > 64) return 1;
+    scene->march_segments = segments;
+    return 0;
+}
+
 extern "C" int photon_scene_set_march_profile(photon_scene_t *scene, int on) {
     if (!scene) return 1;
     return guarded("photon_scene_set_march_profile", [&]() -> int {
@@ -1914,6 +2093,17 @@ extern "C" int photon_scene_march_profile(photon_scene_t *scene, photon_march_pr
     });
 }
 
+// Did any march wave give a segment up (march_group)?  Read wherever the host waits for the device anyway: with the
+// statistics, and at the end of start_ray_tracing.  Never seen; a render it happened in is incomplete and is not returned.
+static int march_error_check(photon_scene *scene) {
+    unsigned e = 0;
+    PH_CHECK(hipMemcpy(&e, scene->d_error, sizeof e, hipMemcpyDeviceToHost));
+    if (!e) return 0;
+    fprintf(stderr, "photon: %u march waves gave up waiting for the previous segment of their group: this render is incomplete\n", e);
+    PH_CHECK(hipMemset(scene->d_error, 0, sizeof e));
+    return 1;
+}
+
 // Sum the counter slots into stats (the caller has made sure the device is done with them).
 static int read_counters(photon_scene *scene, bool have_volume, photon_trace_stats_t *stats) {
     std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
@@ -1921,6 +2111,7 @@ static int read_counters(photon_scene *scene, bool have_volume, photon_trace_sta
     unsigned long long c[CNT_N] = {};
     for (int k = 0; k < kCounterSlots; k++)
         for (int j = 0; j < CNT_N; j++) c[j] += slots[(size_t)k * kCounterStride + j];
+    { const int rc = march_error_check(scene); if (rc) return rc; }
     stats->rays_on_sensor = c[CNT_ON_SENSOR];
     stats->rk_iterations = c[CNT_ITER];
     stats->volume_samples = c[CNT_SAMPLES];
@@ -2305,8 +2496,13 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
                 int rc = 0;
                 if (a.density) rc = cached_volume(a.density_path, interpolation_from_env(), &v, &shared);
                 if (!rc && v) photon_volume_set_weight_bits(v, weight_bits_from_env());
+                const auto tw = std::chrono::steady_clock::now();
                 if (!rc) rc = trace_accumulate(sc, v, a.algorithm, 0, e2 - b, nullptr, false, nullptr);
                 if (!rc && hipDeviceSynchronize() != hipSuccess) rc = 4;
+                if (!rc) rc = march_error_check(sc);
+                if (!rc && verbose())
+                    fprintf(stderr, "photon: device %d: sources [%lld, %lld) traced in %.3f ms\n", devices[k], b, e2,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count());
                 return rc;
             });
         });
@@ -2332,12 +2528,29 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
                 const double *other = scenes[k]->d_acc;
                 if (devices[k] != devices[0]) {
                     if (!d_peer.p && !check(d_peer.alloc(npix), __LINE__)) break;
+                    // direct xGMI copy when the first device may map the other's memory; otherwise the runtime stages the
+                    // copy through the host -- correct, slower, and said out loud
                     int can = 0;
-                    if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) == hipSuccess && can) {
-                        const hipError_t pe = hipDeviceEnablePeerAccess(devices[k], 0);     // direct xGMI copies; already-enabled is fine
+                    bool direct = false;
+                    const hipError_t ce = hipDeviceCanAccessPeer(&can, devices[0], devices[k]);
+                    if (ce == hipSuccess && can) {
+                        const hipError_t pe = hipDeviceEnablePeerAccess(devices[k], 0);
+                        direct = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
                         if (pe != hipSuccess) (void)hipGetLastError();
+                        if (!direct)
+                            fprintf(stderr, "photon: hipDeviceEnablePeerAccess(device %d from device %d) failed: %s; that accumulator is copied through host staging\n",
+                                    devices[k], devices[0], hipGetErrorString(pe));
+                    } else {
+                        if (ce != hipSuccess) (void)hipGetLastError();
+                        fprintf(stderr, "photon: device %d cannot access device %d as a peer (%s); that accumulator is copied through host staging\n",
+                                devices[0], devices[k], ce == hipSuccess ? "hipDeviceCanAccessPeer: no" : hipGetErrorString(ce));
                     }
+                    const auto tc = std::chrono::steady_clock::now();
                     if (!check(hipMemcpyPeer(d_peer.p, devices[0], other, devices[k], npix * sizeof(double)), __LINE__)) break;
+                    if (verbose())
+                        fprintf(stderr, "photon: accumulator of device %d -> device %d: %s copy of %.1f MiB, %.3f ms\n", devices[k], devices[0],
+                                direct ? "direct peer" : "staged", npix * sizeof(double) / 1048576.0,
+                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count());
                     other = d_peer.p;
                 }
                 hipLaunchKernelGGL(add_accumulator_kernel, grid, block, 0, 0, scenes[0]->d_acc, other, npix);
@@ -2507,6 +2720,11 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
         return;
     }
     PH_VOID(hipDeviceSynchronize());
+    if (march_error_check(scene)) {
+        fprintf(stderr, "photon: trace failed; image left untouched\n");
+        cleanup();
+        return;
+    }
     PH_VOID(hipMemcpy(image_array, d_image, npix * sizeof(float), hipMemcpyDeviceToHost));     // .cu:3675
 #undef PH_VOID
     cleanup();

@@ -20,7 +20,8 @@ from .ray_tracing import (RayTracingCall, bind_start_ray_tracing, camera_design_
 DECLARED_SYMBOLS = (
     "start_ray_tracing", "photon_set_device", "photon_device_pci_bus_id", "photon_rand_table", "photon_volume_load_nrrd",
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
-    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_march_queue_group", "photon_trace",
+    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_size",
+    "photon_scene_set_march_segments", "photon_trace",
     "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_set_march_profile", "photon_scene_march_profile",
     "photon_trace_volume_rays", "photon_version",
     # section 3: scene generation on the device
@@ -157,6 +158,8 @@ class PhotonLibrary:
         if self.has_stats_window:
             L.photon_scene_stats_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             L.photon_scene_stats_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(photon_trace_stats_t)]
+        if hasattr(L, "photon_scene_set_march_segments"):
+            L.photon_scene_set_march_segments.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self.has_march_profile = hasattr(L, "photon_scene_march_profile")  # round 4
         if self.has_march_profile:
             L.photon_scene_set_march_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -431,6 +434,10 @@ class Scene:
         self._lib._check(self._lib.lib.photon_scene_stats_end(self.handle, ctypes.c_void_p(int(stream)) if stream else None,
                                                               ctypes.byref(stats)), "photon_scene_stats_end")
         return stats
+
+    def set_march_segments(self, segments: int):
+        """-1 the library's choice, 1 whole marches, n: cut every march of a large launch into n segments (speed only)."""
+        self._lib._check(self._lib.lib.photon_scene_set_march_segments(self.handle, int(segments)), "photon_scene_set_march_segments")
 
     def set_march_profile(self, on: bool):
         """Record wave entry / first-group / exit times of the march launches (measurement; off by default)."""

@@ -30,8 +30,24 @@ def test_bench_line_contract(photon):
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["rays_on_sensor"] > 0 and d["rays_marched"] == d["config"]["rays_total"] == 6 * 100 * 500
     r = d["roofline"]
-    assert r["bound"] == "lds" and r["unit"] == "GB/s" and 0 < r["frac"] <= 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    # the bound is instruction issue, priced with counters measured in THIS run (child rocprofv3 --pmc passes)
+    assert r["bound"] == "valu_issue+power" and 0 < r["frac"] <= 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    v = r["valu_issue"]
+    assert 300 < v["valu_per_wave_sample"] < 600 and 20 < v["lds_per_wave_sample"] < 70 and v["cycles_per_inst"] > 2.0
+    assert v["frac"] == pytest.approx(r["frac"], rel=2e-3)
+    assert 0 < r["lds_pipe"]["frac"] <= 1.0
+    t = r["texel_rate_vs_lds"]                           # SURVEY 8d's algorithmic bytes against the LDS read roof
+    assert t["unit"] == "GB/s" and 0 < t["frac"] <= 1.0 and t["frac"] == pytest.approx(t["achieved"] / t["peak"], rel=1e-3)
+    assert t["rays_per_launch"] == 6 * 100 * 500 and t["rk_iterations_per_ray"] > 40
     assert 0 < r["valu_f32"]["frac"] <= 1.0
+    p = r["march_profile"]                               # wave timing of the launch: start-up, span, drain
+    assert p["launches"] == 2 and p["waves"] > 0 and p["span_ms"] > 0 and 0 <= p["drain_ms"] < p["span_ms"]
+    o = d["gpu_other_configs"]                           # the other BASELINE configs, GPU legs
+    assert set(o) == {"C2", "C3_trilinear", "C3_eighth", "C5_quarter"}
+    assert o["C2"]["rays"] == 1000000 and o["C2"]["kernel_ms"] is None and o["C2"]["rays_on_sensor"] > 0
+    for k in ("C3_trilinear", "C3_eighth", "C5_quarter"):
+        assert o[k]["ms"] > 0 and o[k]["kernel_ms"] > 0 and o[k]["clock_mhz"] > 500 and o[k]["rays_marched"] > 0, k
+    assert o["C5_quarter"]["rays_marched"] < o["C5_quarter"]["rays"]           # doomed rays were skipped
     # measured in this run by the child rocprofv3 passes, not read from a file
     assert isinstance(r["traffic"], int) and r["traffic"] > 0 and r["hbm"]["source"].startswith("measured in this run")
     c = d["cpu_baseline"]
@@ -42,9 +58,10 @@ def test_bench_line_contract(photon):
 
 @pytest.mark.gpu
 def test_bench_weak_mode_and_trilinear(photon):
-    d = _bench("--cpu-sample-rays", "0", "--no-traffic", "--scaling", "weak", "--interp", "linear")
+    d = _bench("--cpu-sample-rays", "0", "--no-traffic", "--no-other-configs", "--scaling", "weak", "--interp", "linear")
     assert d["scaling"] == "weak" and d["roofline"]["traffic"] is None and d["cpu_baseline"] is None
     assert "linear sampler" in d["config"]["workload"] and 0 < d["roofline"]["frac"] <= 1.0
+    assert d["roofline"]["bound"].startswith("lds") and d["roofline"]["valu_issue"] is None and d["gpu_other_configs"] is None
 
 
 @pytest.mark.gpu
@@ -55,7 +72,7 @@ def test_bench_rehearsal_three_ranks_on_one_gpu(photon):
     d = _bench("--gpus", "3", "--rehearse", "--cpu-sample-rays", "0", "--no-traffic", "--check")
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and "rehearsal" in d
     assert d["config"]["rays_total"] == 6 * 100 * 500 == d["rays_marched"]      # every source traced exactly once
-    assert d["roofline"]["rays_per_launch"] == 2 * 100 * 500                    # rank 0's third of the sources
+    assert d["roofline"]["texel_rate_vs_lds"]["rays_per_launch"] == 2 * 100 * 500      # rank 0's third of the sources
     assert d["rays_on_sensor"] == 6 * 100 * 500
     assert d["check"]["sources"] == 600 and d["check"]["rel_l2"] <= 1e-5
     w = _bench("--gpus", "2", "--rehearse", "--scaling", "weak", "--cpu-sample-rays", "0", "--no-traffic")

@@ -106,10 +106,20 @@ def test_march_work_queues_partition_every_launch():
     f = lib.photon_march_queue_group
     f.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
     f.restype = ctypes.c_uint
-    for n_groups in (1, 127, 128, 129, 1023, 8 * 128 + 5, 64 * 128, 64 * 128 + 1, 19532):
+    size = lib.photon_march_queue_size
+    size.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    size.restype = ctypes.c_uint
+    lib.photon_march_queue_count.restype = ctypes.c_uint
+    subs = lib.photon_march_queue_count() // 8
+    assert subs == 4
+    assert f(0, 8, 0) == 0xFFFFFFFF and f(0, 0, subs) == 0xFFFFFFFF and size(100, 0, subs) == 0xFFFFFFFF      # out of range: refused, not aliased
+    for n_groups in (1, 127, 128, 129, 1023, 8 * 128 + 5, 32 * 128 - 1, 32 * 128, 64 * 128, 64 * 128 + 1, 19532):
         seen = np.zeros(n_groups, np.int32)
         for x in range(8):
-            for sub in range(4):
+            for sub in range(subs):
+                # a segmented launch hands out size x S items per queue, item k = segment k // size of group k % size:
+                # the closed form must count exactly the groups the queue's own enumeration finds below the launch's end
+                assert size(n_groups, x, sub) == sum(1 for k in range(n_groups) if f(k, x, sub) < n_groups) if n_groups < 2000 else True
                 last, k = -1, 0
                 while True:
                     g = f(k, x, sub)
@@ -120,4 +130,5 @@ def test_march_work_queues_partition_every_launch():
                     seen[g] += 1
                     assert (g // 128) % 8 == x and (g // 128 // 8) % 4 == sub
                     k += 1
+                assert k == size(n_groups, x, sub), (n_groups, x, sub)
         assert (seen == 1).all(), n_groups

@@ -1,14 +1,16 @@
-#!/usr/bin/env python3
-"""Print the key numbers of bench.py JSON lines: tools/bench_line.py LOG [LOG...]"""
+"""One line per bench log: the numbers A/B runs are compared on.   python tools/bench_line.py <log> [...]"""
 import json
 import sys
 
 for path in sys.argv[1:]:
-    try:
-        lines = [x for x in open(path) if x.startswith("{")]
-        d = json.loads(lines[-1])
+    for ln in open(path):
+        if not ln.startswith("{"):
+            continue
+        d = json.loads(ln)
         r = d["roofline"]
-        print(path, "Mrays/s", d["value"], "ms/step", d["ms_per_step"], "march_ms", r["kernel_ms"], "frac", r.get("frac"),
-              "clock_mhz", r.get("clock_mhz"), "frac_at_clock", r.get("frac_at_clock"), "wave_ms", r.get("wave_lifetime_ms"), "gens", r.get("wave_generations"), "power_w", (r.get("board_power") or {}).get("median_w"), "cap", (r.get("board_power") or {}).get("cap_w"), "check", d.get("check"))
-    except Exception as e:                                     # noqa: BLE001
-        print(path, "unreadable:", e)
+        t = r.get("texel_rate_vs_lds") or r                      # lines written before round 4 carry these at the top level
+        p = r.get("march_profile") or {}
+        print(path, "Mrays/s", d["value"], "ms/step", d["ms_per_step"], "march_ms", r["kernel_ms"], "clock_mhz", r.get("clock_mhz"),
+              "texel_frac", t.get("frac"), "at_clock", t.get("frac_at_clock"), "wave_ms", r.get("wave_lifetime_ms"),
+              "gens", r.get("wave_generations"), "span/drain_ms", p.get("span_ms"), p.get("drain_ms"),
+              "power_w", (r.get("board_power") or {}).get("median_w"), "check", d.get("check"))

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""First-contact self-check for a node with several MI355X: run this BEFORE trusting any scaling number.
+
+    python tools/multigpu_selfcheck.py [--gpus N] [--dots D] [--volume V] [--steps K]
+
+What is being distributed is the reference's chunk loop over light-field sources (parallel_ray_tracing.cu:3505-3558):
+sources are independent, the sensor image is a sum.  Two paths do it, and both are checked here on the C3 job
+(BOS, D dots x 100 points x 500 rays through a V^3 volume, tricubic RK4):
+
+  1. inside ONE start_ray_tracing call (PHOTON_DEVICES=all: one host thread per device, shard-only uploads, accumulators
+     summed on the first device through hipMemcpyPeer): image vs the same call on device 0 alone, <= 1e-5 relative L2;
+     PHOTON_VERBOSE=1 reports, per device, the time of its shard and whether its accumulator travelled by a direct peer copy
+     or through host staging (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess state);
+  2. one process per GPU (bench.py --gpus N, RCCL sum-reduce over xGMI), strong and weak scaling, K steps, with the
+     bench's own parity check: 40 sources against the CPU oracle and the reduced image against the job on one GPU.
+
+One PASS / FAIL line per item; exit status 0 only if every item passed.  With one GPU the same code runs in its degenerate
+form (PHOTON_DEVICES=0,0: two shards side by side on the device; bench at N = 1).  This parent process never initialises
+the GPU (it only counts devices): every item is a child process.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-5
+
+
+def child_devices(args):
+    """Item 1, in a child process: single-device image vs PHOTON_DEVICES image of the same call."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch  # noqa: F401  (first: one HIP runtime per process)
+    from photon_amd import scenes
+    from photon_amd.library import PhotonLibrary
+    lib = PhotonLibrary()
+    work = os.path.join(tempfile.gettempdir(), "photon_bench")
+    os.makedirs(work, exist_ok=True)
+    path = os.path.join(work, f"bos_{args.volume}.nrrd")
+    if not os.path.exists(path):
+        rho, sp, org = scenes.bos_volume(args.volume)
+        scenes.write_nrrd(path, rho, sp, org)
+    call = scenes.bos_scene(n_dots=args.dots, points_per_dot=100, rays_per_source=500, density_grad_filename=path)
+    os.environ["PHOTON_INTERP"] = "cubic"
+    os.environ.pop("PHOTON_DEVICES", None)
+    one = lib.render(call).astype(np.float64)
+    os.environ["PHOTON_DEVICES"] = args.child_devices
+    os.environ["PHOTON_VERBOSE"] = "1"
+    many = lib.render(call).astype(np.float64)
+    rel = float(np.linalg.norm(many - one) / np.linalg.norm(one))
+    print(json.dumps({"rel_l2": rel, "devices": args.child_devices, "rays": call.num_rays, "image_sum": float(one.sum())}), flush=True)
+
+
+def run(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PHOTON_DEVICES"):
+        e.pop(k, None)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.update(env or {})
+    r = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
+    line = next((json.loads(ln) for ln in out.splitlines() if ln.startswith("{")), None)
+    return r.returncode, line, out, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="GPUs to use (default: every device of the node)")
+    ap.add_argument("--dots", type=int, default=200, help="BOS dots of the job (200 = the headline 1e7-ray job)")
+    ap.add_argument("--volume", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--child-devices", default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.child_devices is not None:
+        return child_devices(args)
+    import torch
+    have = torch.cuda.device_count()              # does not initialise the GPU
+    n = args.gpus or have
+    if have < 1 or n > have:
+        print(f"FAIL devices: {n} GPUs asked for, {have} visible")
+        return 1
+    ok = True
+    # ---- 1. PHOTON_DEVICES inside one start_ray_tracing call ------------------------------------------------------------
+    devices = ",".join(str(d) for d in range(n)) if n > 1 else "0,0"
+    rc, line, out, err = run([sys.executable, os.path.abspath(__file__), "--child-devices", devices, "--dots", str(args.dots),
+                              "--volume", str(args.volume)])
+    for ln in err.splitlines():                   # per-device shard times, peer-access state of every accumulator copy
+        if ln.startswith("photon:") and ("device" in ln or "devices" in ln):
+            print("   ", ln)
+    staged = [ln for ln in err.splitlines() if "host staging" in ln or "staged copy" in ln]
+    good = rc == 0 and line is not None and line["rel_l2"] <= TOL
+    ok &= good
+    print(f"{'PASS' if good else 'FAIL'} start_ray_tracing with PHOTON_DEVICES={devices}: "
+          + (f"rel L2 vs one device {line['rel_l2']:.2e} (<= {TOL:g}), {line['rays']} rays" if line else f"no result (rc {rc}): {err[-400:]}"))
+    if n > 1:
+        good = not staged
+        ok &= good
+        print(f"{'PASS' if good else 'FAIL'} peer copies: " + ("every accumulator travelled by a direct peer copy" if good else
+                                                               f"{len(staged)} accumulator(s) went through host staging"))
+    # ---- 2. one process per GPU, RCCL reduce ----------------------------------------------------------------------------
+    for scaling in ("strong", "weak"):
+        rc, line, out, err = run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(args.steps), "--warmup", "2",
+                                  "--scaling", scaling, "--check", "--dots", str(args.dots), "--volume", str(args.volume), "--cpu-sample-rays", "0",
+                                  "--no-traffic", "--no-other-configs"])
+        chk = (line or {}).get("check") or {}
+        good = rc == 0 and line is not None and line["n_gpus"] == n and chk.get("rel_l2", 1) <= TOL and \
+            (n == 1 or chk.get("sharded_vs_single_gpu_rel_l2", 1) <= TOL) and (n == 1 or line["config"]["rccl_ranks"] == n)
+        ok &= good
+        print(f"{'PASS' if good else 'FAIL'} bench.py --gpus {n} --scaling {scaling}: "
+              + (f"{line['value']:.1f} Mrays/s, {line['ms_per_step']:.2f} ms per step, oracle slice {chk.get('rel_l2', float('nan')):.2e}"
+                 + (f", reduced image vs one GPU {chk.get('sharded_vs_single_gpu_rel_l2', float('nan')):.2e}, {line['config']['rccl_ranks']} RCCL ranks" if n > 1 else "")
+                 if line else f"no result (rc {rc}): {err[-400:]}"))
+    print("ALL PASS" if ok else "SOME ITEMS FAILED")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
