@@ -178,7 +178,9 @@ typedef struct photon_volume_info_t {
     int interpolation;      /* 1 trilinear, 2 tricubic B-spline */
 } photon_volume_info_t;
 
-/* Per-trace counters (filled from device atomics; for roofline accounting). */
+/* Per-trace counters (filled from device atomics; for roofline accounting).  LAYOUT FROZEN at 72 bytes (round 3): the
+ * library writes sizeof(photon_trace_stats_t) bytes through the caller's pointer, so the struct never grows again -- later
+ * measurements come through structs that carry their own size (photon_march_profile_t). */
 typedef struct photon_trace_stats_t {
     uint64_t rays_launched;
     uint64_t rays_on_sensor;        /* rays that reached the splat stage inside the sensor */
@@ -323,6 +325,8 @@ int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_trac
  * its stream and lets the counters run; _end waits for the stream and returns the SUMS over the window's traces
  * (march_ms, total_ms, the counters; shader_clock_mhz over all march waves; traces = number of calls).  The reference
  * prints one wall-clock time per call instead (parallel_ray_tracing.cu:3498-3503, 3678-3684). */
+/* The window belongs to the stream it was opened on: a photon_trace of this scene on another stream, or more than 65536
+ * traces in one window, is refused. */
 int photon_scene_stats_begin(photon_scene_t *scene, void *stream);
 int photon_scene_stats_end(photon_scene_t *scene, void *stream, photon_trace_stats_t *stats);
 

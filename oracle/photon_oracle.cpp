@@ -1103,7 +1103,7 @@ Ray optical_system(const element_data_t *elems, const float (*centers)[3], const
     return ray;
 }
 
-struct Image {                      // per-thread double accumulator
+struct alignas(64) Image {          // per-thread double accumulator (a cache line of its own: taps is bumped per splat)
     int W, H;
     std::vector<double> acc;
     uint64_t taps = 0;
@@ -1384,12 +1384,19 @@ static void render_core(Scene &sc, const Volume *volp, float *image_array, bool 
             ipos.assign((size_t)num_lightrays_save * inter_slots, mk3(NANF, NANF, NANF));
             idir.assign((size_t)num_lightrays_save * inter_slots, mk3(NANF, NANF, NANF));
         }
-#pragma omp parallel for schedule(dynamic, 64)
-        for (int64_t gid = 0; gid < num_rays; gid++) {                  // one iteration = one GPU thread
-            int tid = 0;
+        // per-thread counters live on the thread's own stack inside the parallel region and are merged once: as adjacent
+        // elements of a vector they shared cache lines, and a counter bumped at every texel sample made sixteen threads
+        // run barely faster than three (bench.py's cpu_baseline, round 3)
+#pragma omp parallel
+        {
+        int tid = 0;
 #ifdef _OPENMP
-            tid = omp_get_thread_num();
+        tid = omp_get_thread_num();
 #endif
+        MarchCount mc_local{0, 0};
+        uint64_t on_local = 0;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t gid = 0; gid < num_rays; gid++) {                  // one iteration = one GPU thread
             const int64_t lp = gid / rps;
             const int lr = (int)(gid % rps);
             const int64_t source = n_min + lp;
@@ -1398,9 +1405,12 @@ static void render_core(Scene &sc, const Volume *volp, float *image_array, bool 
             const bool dump = save_lightrays && gid < num_lightrays_save;
             InterRec ir;
             if (inter && dump) ir = InterRec{&ipos[(size_t)gid * inter_slots], &idir[(size_t)gid * inter_slots], inter_slots};
-            trace_one(sc, volp, ray_tracing_algorithm, source, lr, imgs[tid], mcs[tid], dump ? &out : nullptr,
-                      on_sensor[tid], &ir);
+            trace_one(sc, volp, ray_tracing_algorithm, source, lr, imgs[tid], mc_local, dump ? &out : nullptr,
+                      on_local, &ir);
             if (dump) { fpos[gid] = out.pos; fdir[gid] = out.dir; }
+        }
+        mcs[tid].iterations += mc_local.iterations; mcs[tid].samples += mc_local.samples;
+        on_sensor[tid] += on_local;
         }
         if (save_lightrays) {
             write_dump(lightray_position_save_path, "pos_", (int)k, fpos);

@@ -19,7 +19,8 @@ LIB_NAME = "libparallel_ray_tracing.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 
 SOURCES = [os.path.join(CSRC, "photon_core.hip"), os.path.join(CSRC, "photon_sort.hip")]
-HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp", "device_volume_coop.hpp", "device_volume_extra.hpp", "device_optics.hpp")] + [
+HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp", "device_volume_coop.hpp", "device_volume_extra.hpp", "device_optics.hpp",
+                                            "photon_sort.hpp")] + [
     os.path.join(ROOT, "include", "parallel_ray_tracing.h"),
     os.path.join(ROOT, "include", "photon_det_math.h"),
     os.path.join(ROOT, "include", "photon_philox.h"),
@@ -51,9 +52,12 @@ def hipcc_path() -> str:
 def rocm_lib_dir() -> str:
     """lib/ of the ROCm installation whose hipcc compiles the library ($ROCM_PATH, else the prefix hipcc sits in,
     symlinks unresolved: /opt/rocm rather than /opt/rocm-7.2.0) -- the RUNPATH and the -L of the link."""
-    prefix = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(hipcc_path()))
-    lib = os.path.join(prefix, "lib")
-    return lib if os.path.isdir(lib) else "/opt/rocm/lib"
+    for prefix in (os.environ.get("ROCM_PATH"), os.path.dirname(os.path.dirname(hipcc_path())), "/opt/rocm"):
+        lib = os.path.join(prefix, "lib") if prefix else None
+        # a hipcc found as /usr/bin/hipcc names /usr/lib, which exists but holds no HIP runtime: ask for the library itself
+        if lib and os.path.exists(os.path.join(lib, "libamdhip64.so")):
+            return lib
+    return "/opt/rocm/lib"
 
 
 def link_flags():

@@ -36,6 +36,12 @@ namespace photon {
 #ifndef PHOTON_TILE_REUSE
 #define PHOTON_TILE_REUSE 1
 #endif
+#ifndef PHOTON_PREV_STASH
+#define PHOTON_PREV_STASH 1         // the trilinear branches' val_prev in a per-lane LDS slot (1) or in four VGPRs (0)
+#endif
+#ifndef PHOTON_TILE_LANE_PIN
+#define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch (1) or left to the compiler to hoist (0)
+#endif
 // Row pitch of the brick in LDS, in texels.  The brick is 8 texels wide; with a pitch of 8 the 16-byte reads of lanes
 // whose blocks sit two rows apart land on the same four banks (a ds_read_b128 serves 16 lanes per LDS cycle from 64
 // banks: texel index mod 16 names the bank group, and 8 * dj mod 16 only takes two values).  A pitch of 12 makes
@@ -48,7 +54,9 @@ constexpr int kBrickPitch = PHOTON_BRICK_PITCH;                  // texels betwe
 constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels between consecutive z-slabs
 // per wave: the tile (64 texels reserved; trilinear uses 8) + the brick: 8x8x4 texels for the tricubic sampler, 8x8x2 for
 // the trilinear one -- 7 KiB against 4 KiB, i.e. at most 5 against 10 workgroups of four waves in a CU's 160 KiB
-template <int INTERP> constexpr int wave_lds_texels() { return 64 + (INTERP == 2 ? 4 : 2) * kBrickSlab; }
+// -- and, for the trilinear kernels, one more 16-byte slot per lane behind the brick: the last value the lane sampled (PrevStash)
+template <int INTERP> constexpr int wave_lds_texels() { return 64 + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 ? 64 : 0); }
+constexpr int kPrevStashOffset = 64 + 2 * kBrickSlab;           // texel slot of lane 0's stash in a trilinear wave's LDS area
 constexpr int kWaveLdsTexels = wave_lds_texels<2>();
 
 // 64-tap sum (slab order) over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
@@ -106,6 +114,9 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 
 #ifndef PHOTON_DPP_SLAB
 #define PHOTON_DPP_SLAB 1
+#endif
+#ifndef PHOTON_DUAL_SLAB
+#define PHOTON_DUAL_SLAB 0          // experiment: z-slabs 1 and 2 of the hybrid chain interleaved (two accumulators)
 #endif
 #ifndef PHOTON_DPP_ROWS
 #define PHOTON_DPP_ROWS 4           // rows of z-slab 0 (four taps each) served from registers; the rest of the slab comes from LDS
@@ -199,6 +210,16 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #else
 #define PH_DPP_ROWS_TEXT PH_DPP_ROW0 PH_DPP_ROW1 PH_DPP_ROW2 PH_DPP_ROW3
 #endif
+// the four texels the asm block reads ahead: row 0 of slab 1 -- or, with slabs 1 and 2 interleaved, their first two taps each
+#if PHOTON_DUAL_SLAB
+#define PH_DS_OFF1 "256"
+#define PH_DS_OFF2 "16"
+#define PH_DS_OFF3 "272"
+#else
+#define PH_DS_OFF1 "16"
+#define PH_DS_OFF2 "32"
+#define PH_DS_OFF3 "48"
+#endif
 __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const float (&wx)[4], const float (&wy)[4],
                                                 const float (&wz)[4]) {
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -214,9 +235,9 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
     const unsigned lds = (unsigned)(size_t)blk + 64u * R;           // LDS byte address of the first row read from the tile
     asm volatile(
             "ds_read_b128 %4, %28\n\t"
-            "ds_read_b128 %5, %28 offset:16\n\t"
-            "ds_read_b128 %6, %28 offset:32\n\t"
-            "ds_read_b128 %7, %28 offset:48\n\t"
+            "ds_read_b128 %5, %28 offset:" PH_DS_OFF1 "\n\t"
+            "ds_read_b128 %6, %28 offset:" PH_DS_OFF2 "\n\t"
+            "ds_read_b128 %7, %28 offset:" PH_DS_OFF3 "\n\t"
             "s_nop 4\n\t"
             PH_DPP_ROWS_TEXT
             "s_waitcnt lgkmcnt(0)"
@@ -229,8 +250,44 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
     f4 acc = f4{0, 0, 0, 0};
     if (R == 4) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};     // slab 0 complete (else: at r == 3 below)
     float w0 = wxy[0][0];
+#if PHOTON_DUAL_SLAB
+    // EXPERIMENT (round 4, verdict item 7): z-slabs 1 and 2 interleaved tap by tap -- two accumulators, eight independent
+    // multiply-add chains in flight instead of four, each chain in its own order (same bits); slab 3 alone afterwards.  The
+    // texel ring stays four slots: slot j % 4 holds the texel of the j-th tap in ISSUE order -- j = 2 * (4 b + a) + (slab - 1)
+    // -- refilled three taps ahead; the asm block above read taps 0-3 (its offsets: PH_DS_OFF*), and the last four refills
+    // are row 0 of slab 3 for the loop below.
+    static_assert(R == 4, "PHOTON_DUAL_SLAB needs all of slab 0 from registers");
+    {
+        f4 s2 = f4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const int slab = 1 + (j & 1), bb = (j >> 1) >> 2, aa = (j >> 1) & 3;
+            const f4 ta = t[j & 3];
+            const float w = (aa == 0 && bb == 0) ? w0 : wxy[bb][aa];
+            if (slab == 1) {
+                if (aa == 0 && bb == 0) s = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
+                else s = f4{fmaf(w, ta.x, s.x), fmaf(w, ta.y, s.y), fmaf(w, ta.z, s.z), fmaf(w, ta.w, s.w)};
+                asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w) : : "memory");
+            } else {
+                if (aa == 0 && bb == 0) s2 = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
+                else s2 = f4{fmaf(w, ta.x, s2.x), fmaf(w, ta.y, s2.y), fmaf(w, ta.z, s2.z), fmaf(w, ta.w, s2.w)};
+                asm volatile("" : "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w) : : "memory");
+            }
+            const int n = j + 4;                                    // the tap this slot serves next
+            if (n < 32) t[j & 3] = ldtexel(blk + (1 + (n & 1)) * 16 + ((n >> 1) >> 2) * 4 + ((n >> 1) & 3));
+            else t[j & 3] = ldtexel(blk + 48 + (n - 32));           // slab 3, row 0
+            asm volatile("" : "+v"(w0) : : "memory");
+        }
+        acc = f4{fmaf(wz[1], s.x, acc.x), fmaf(wz[1], s.y, acc.y), fmaf(wz[1], s.z, acc.z), fmaf(wz[1], s.w, acc.w)};
+        acc = f4{fmaf(wz[2], s2.x, acc.x), fmaf(wz[2], s2.y, acc.y), fmaf(wz[2], s2.z, acc.z), fmaf(wz[2], s2.w, acc.w)};
+        asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
+    }
+#pragma unroll
+    for (int r = 12; r < 16; r++) {                                 // slab 3 from LDS, as in cubic_taps_lds
+#else
 #pragma unroll
     for (int r = R; r < 16; r++) {                                  // the rest of the tile from LDS, as in cubic_taps_lds
+#endif
         const int b = r & 3, c = r >> 2;
 #pragma unroll
         for (int a = 0; a < 4; a++) {
@@ -405,14 +462,19 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
             if (!PHOTON_TILE_REUSE || ld.i != parked.ti || ld.j != parked.tj || ld.k != parked.tk) {  // wave-uniform: not parked yet
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 8) {
+                    int l = lane;
+#if PHOTON_TILE_LANE_PIN
+                    asm volatile("" : "+v"(l));                 // keep the tile's lane offsets out of the march loop's live registers:
+                                                                // hoisted as loop invariants they were spilled, and every fetch reloaded them from scratch
+#endif
                     const int ci = (int)__int_as_float(ld.i), cj = (int)__int_as_float(ld.j), ck = (int)__int_as_float(ld.k);
-                    const int tx = clampi(ci + (lane & 1), 0, v.nx - 1), ty = clampi(cj + ((lane >> 1) & 1), 0, v.ny - 1),
-                              tz = clampi(ck + ((lane >> 2) & 1), 0, v.nz - 1);
+                    const int tx = clampi(ci + (l & 1), 0, v.nx - 1), ty = clampi(cj + ((l >> 1) & 1), 0, v.ny - 1),
+                              tz = clampi(ck + ((l >> 2) & 1), 0, v.nz - 1);
                     const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
                     const f4 o = f4{pair_swap(t.x), pair_swap(t.y), pair_swap(t.z), pair_swap(t.w)};     // the pair's other texel
-                    const bool hi = (lane & 1) != 0;
-                    *reinterpret_cast<float4 *>(blk + lane) = make_float4(hi ? t.x - o.x : t.x, hi ? t.y - o.y : t.y,
-                                                                          hi ? t.z - o.z : t.z, hi ? t.w - o.w : t.w);
+                    const bool hi = (l & 1) != 0;
+                    *reinterpret_cast<float4 *>(blk + l) = make_float4(hi ? t.x - o.x : t.x, hi ? t.y - o.y : t.y,
+                                                                       hi ? t.z - o.z : t.z, hi ? t.w - o.w : t.w);
                 }
                 __builtin_amdgcn_wave_barrier();
                 parked.ti = ld.i; parked.tj = ld.j; parked.tk = ld.k;
@@ -533,10 +595,31 @@ __device__ __forceinline__ void count_iterations(MarchCount &mc, unsigned long l
 __device__ __forceinline__ void count_samples(WaveCount &mc, unsigned long long m) { mc.samples += (unsigned)__popcll(m); }
 __device__ __forceinline__ void count_iterations(WaveCount &mc, unsigned long long m) { mc.iterations += (unsigned)__popcll(m); }
 
+// val_prev -- the last value a lane sampled, which the trilinear branches fall back on when a blend comes out below the
+// volume's minimum (.h:1056-1065) -- lives in LDS, not in registers (round 4): it is written after every sample (one
+// ds_write_b128 per lane, into the lane's own slot behind the brick) and read only in that rare repair.  Four VGPRs less
+// across the whole march loop: the trilinear RK4 kernel sits on its 96-register budget, and with the resume state of the
+// segmented march on top it spilled 15 of them into the loop.
+#if PHOTON_PREV_STASH
+struct PrevVal {
+    f4 *slot;
+    __device__ __forceinline__ void init(f4 *blk, f4 v) { slot = blk + kPrevStashOffset + (threadIdx.x & 63); set(v); }
+    __device__ __forceinline__ void set(f4 v) { *reinterpret_cast<float4 *>(slot) = make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ f4 get() const { return ldtexel(slot); }
+};
+#else
+struct PrevVal {                                                // A/B form: the value in four VGPRs, as in rounds 1-3
+    f4 v;
+    __device__ __forceinline__ void init(f4 *, f4 x) { v = x; }
+    __device__ __forceinline__ void set(f4 x) { v = x; }
+    __device__ __forceinline__ f4 get() const { return v; }
+};
+#endif
+
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
 template <int INTERP, bool QUANT, class CNT>
 __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need, f3 lookup,
-                                          const f4 &val_prev, float data_min, CNT &mc, Parked &parked) {
+                                          const PrevVal &prev, float data_min, CNT &mc, Parked &parked) {
     f4 val = INTERP == 1 ? tex3d_linear_coop<QUANT>(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked)
                          : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked);
     count_samples(mc, need);
@@ -544,6 +627,7 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
         const unsigned long long low = need & ballot(val.w < data_min);
         if (low != 0) {                                         // wave-uniform, rare: a blend below the volume's minimum
             const float ambient = 1.000277;
+            const f4 val_prev = prev.get();                     // the lane's last sampled value (parked in LDS)
             const unsigned long long repair = low & ballot(val_prev.w == 0);
             if (repair != 0) {
                 const f4 t = tex3d_linear_coop<QUANT>(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
@@ -605,10 +689,12 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
     unsigned trips = rs.trips_base;                             // wave-uniform; no lane's loop_ctr exceeds it
     const unsigned trips_end = rs.max_trips == ~0u ? ~0u : trips + rs.max_trips;
     Parked parked = parked_none();
-    // val_prev: the last value a lane sampled (n-1 form), for the linear branch's repair.  Updated unpredicated; the
-    // only live lanes that sit samples out are spinning ones, which have not sampled yet (a ray spins only on its first
-    // iteration, see inside_mask) -- theirs is put back to its initial zeros at the end of such a trip.
-    f4 val_prev = rs.val_prev;
+    // val_prev: the last value a lane sampled (n-1 form), for the linear branch's repair: in the lane's LDS slot
+    // (PrevVal).  Updated unpredicated; the only live lanes that sit samples out are spinning ones, which have not
+    // sampled yet (a ray spins only on its first iteration, see inside_mask) -- theirs is put back to its initial zeros at
+    // the end of such a trip.
+    PrevVal prev{};
+    if (INTERP == 1) prev.init(blk, rs.val_prev);               // the tricubic branches have no such fallback
     unsigned long long active = ballot(active_lane);
     unsigned long long first = active & ballot(loop_ctr == 0);  // lanes with loop_ctr == 0
     while (active != 0 && trips < trips_end) {                  // wave-uniform loop
@@ -626,7 +712,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
             go = alive & access;
             spin = alive & ~access;                             // the reference's `continue`: step forward, retry next trip
         }
-        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
         if (INTERP == 2) {                                      // .h:1220-1227
             const unsigned long long low = go & ballot(val.w < u.data_min);
             spin |= low;
@@ -647,36 +733,36 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         f3 T_n = n_a * rdir;
         const f3 A = delta_t * mk3(n_a * val.x, n_a * val.y, n_a * val.z);
         f3 spos = rpos + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;       // .h:1088
-        if (INTERP == 1) val_prev = f4{val.x, val.y, val.z, n_a - 1};
+        if (INTERP == 1) prev.set(f4{val.x, val.y, val.z, n_a - 1});
         // ---------------- sample B ----------------
         lookup = lookup_index_u(spos, u);
         unsigned long long in = inside_mask(spos, u);           // .h:1094-1101: outside = `break`, nothing committed
         active &= ~go | in;
         go &= in;
-        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
         const float n_b = val.w + 1;
         const f3 B = delta_t * mk3(n_b * val.x, n_b * val.y, n_b * val.z);
         spos = rpos + delta_t * T_n + (0.5f * delta_t) * B;                     // .h:1131
-        if (INTERP == 1) val_prev = f4{val.x, val.y, val.z, n_b - 1};
+        if (INTERP == 1) prev.set(f4{val.x, val.y, val.z, n_b - 1});
         // ---------------- sample C ----------------
         lookup = lookup_index_u(spos, u);
         in = inside_mask(spos, u);                              // .h:1135-1141
         active &= ~go | in;
         go &= in;
-        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
         const float n_c = val.w + 1;
         const f3 C = delta_t * mk3(n_c * val.x, n_c * val.y, n_c * val.z);
-        if (INTERP == 1) val_prev = f4{val.x, val.y, val.z, n_c - 1};
+        if (INTERP == 1) prev.set(f4{val.x, val.y, val.z, n_c - 1});
         if (lane_of(go)) {                                      // the iteration completed: commit
             rpos = rpos + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));         // .h:1169
             T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);                         // .h:1170
             rdir = normalize(T_n / (INTERP == 1 ? n_a : n_c));                         // .h:1178 / 1276
         }
         count_iterations(mc, go);
-        if (INTERP == 1 && spin != 0) { if (lane_of(spin)) val_prev = f4{0, 0, 0, 0}; }
+        if (INTERP == 1 && spin != 0) { if (lane_of(spin)) prev.set(f4{0, 0, 0, 0}); }
     }
     rs.loop_ctr = loop_ctr; rs.spins = spins;
-    if (INTERP == 1) rs.val_prev = val_prev;
+    if (INTERP == 1) rs.val_prev = prev.get();
     return active;
 }
 
@@ -695,7 +781,8 @@ __device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &r
     unsigned trips = rs.trips_base;
     const unsigned trips_end = rs.max_trips == ~0u ? ~0u : trips + rs.max_trips;
     Parked parked = parked_none();
-    f4 val_prev = rs.val_prev;
+    PrevVal prev{};                                             // val_prev in LDS, as in rk4_coop
+    if (INTERP == 1) prev.init(blk, rs.val_prev);
     unsigned long long active = ballot(active_lane);
     unsigned long long first = active & ballot(loop_ctr == 0);
     while (active != 0 && trips < trips_end) {
@@ -712,7 +799,7 @@ __device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &r
             go = alive & access;
             spin = alive & ~access;
         }
-        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, val_prev, u.data_min, mc, parked);
+        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
         if (INTERP == 2) {                                      // .h:916-923
             const unsigned long long low = go & ballot(val.w < u.data_min);
             spin |= low;
@@ -738,7 +825,7 @@ __device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &r
                 const float current_n = 1 + val.w;
                 rdir = rdir + u.step * mk3(val.x, val.y, val.z);               // .h:869 (not renormalised)
                 rpos = rpos + u.step / current_n * rdir;                       // .h:875
-                val_prev = val;
+                prev.set(val);
             }
         } else {
             if (lane_of(go)) {
@@ -751,7 +838,7 @@ __device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &r
         count_iterations(mc, go);
     }
     rs.loop_ctr = loop_ctr; rs.spins = spins;
-    if (INTERP == 1) rs.val_prev = val_prev;
+    if (INTERP == 1) rs.val_prev = prev.get();
     return active;
 }
 

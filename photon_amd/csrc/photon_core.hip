@@ -44,6 +44,7 @@
 #include "device_volume.hpp"
 #include "device_volume_coop.hpp"
 #include "device_volume_extra.hpp"
+#include "photon_sort.hpp"
 
 using namespace photon;
 
@@ -421,6 +422,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #ifndef PHOTON_MARCH_WAVES_LINEAR
 #define PHOTON_MARCH_WAVES_LINEAR 5     // a sixth wave (80 VGPRs) costs 20 spilled dwords in the RK4 loop: 27.7 vs 26.6 ms on C3 (r02)
 #endif
+#ifndef PHOTON_MARCH_WAVES_NOISE
+#define PHOTON_MARCH_WAVES_NOISE 3      // the gradient-noise instantiations (Philox + Box-Muller in f64 inside the loop) need ~130 VGPRs: at five
+#endif                                  // waves per SIMD they spilled 46-70 of them into the loop (176-208 B of scratch per lane); three waves, no spill
+template <int INTERP, bool NOISE> constexpr int march_waves() { return NOISE ? PHOTON_MARCH_WAVES_NOISE : (INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES); }
 // Shader-clock stamp of a wave: s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
 // (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The chip lowers its clock under load, by an amount that differs from
 // device to device; the ratio of the two deltas, summed over the waves of a launch, is the clock the march actually ran
@@ -526,7 +531,7 @@ __host__ __device__ inline unsigned march_queue_size(unsigned n_groups, unsigned
 // Agent-scope relaxed accesses (global_load / global_store ... sc1): the loads bypass this CU's L1, the stores write
 // through the XCD's L2 -- how the ray state travels from the wave that marched one segment of a group to the wave, on any
 // CU of any XCD, that marches the next (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload, the storing wave's
-// own vmcnt(0), an sc1 flag; the reader polls the flag with an sc1 load, then an agent acquire, then sc1 loads).
+// own vmcnt(0), an sc1 flag; the reader polls the flag with an sc1 load, then loads the payload with sc1 loads only).
 template <class T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr int kSegPollMax = 1 << 20;                            // polls (~2 us each) before a wave gives a segment up: the exit every wave reaches
@@ -543,7 +548,9 @@ constexpr unsigned kSegDone = 0xffu;                            // seg_flag: eve
 // (MarchResume), so the bits do not change.  A segment's wave may have to wait for the wave still marching the previous
 // one (only when a launch has fewer groups than the chip holds waves: the host does not segment those): it polls the
 // group's flag, bounded -- a wave that gives up counts itself in MarchArgs::error and leaves (march_error_check).
-template <int ALGO, int INTERP, bool SAVE, bool NOISE>
+// SEG: this instantiation handles segmented launches (MarchArgs::segments > 1); the whole-march instantiations carry none of
+// the resume code -- the trilinear RK4 kernel, which sits on its 96-register budget, spilled 15 VGPRs into its loop with it.
+template <int ALGO, int INTERP, bool SAVE, bool NOISE, bool SEG>
 __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsigned n_rays, f4 *tile, WaveTotals &tot) {
     unsigned long long clk0, real0, clk1, real1;
     clock_stamp(clk0, real0);
@@ -561,7 +568,7 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
     MarchArgsPtr a = march_args();
     MarchResume rs = resume_fresh();
     {
-        const bool fresh = seg == 0;                            // wave-uniform
+        const bool fresh = !SEG || seg == 0;                    // wave-uniform
         const RayStateDev st = load_arg(&a->st);
         if (!fresh) {
             // the previous segment of this group: handed out before this one, to a wave that is running -- normally long done
@@ -580,7 +587,11 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
                 __builtin_amdgcn_s_sleep(8);
             }
             if ((flag & 0xffu) == kSegDone) return;             // wave-uniform: no ray of this group is still in the volume
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // No agent-scope acquire here: every load of the handed-off words below is an sc1 load (bypasses this CU's L1),
+            // every one of them was stored sc1 and drained before the flag, and the flag itself was polled sc1 -- the guide's
+            // conditions for leaving the buffer_inv out, checked for exactly this pattern (lines shared between groups, five
+            // workgroups per CU, uneven arrivals) by tools/ubench/xcd_handoff.hip: 0 stale words of 7.4e7 with or without it.
+            // An acquire per segment start invalidates the L1 under the CU's nineteen other waves' texel blocks.
         }
         if (has_ray) {
             p = mk3(ld_agent(&st.px[r]), ld_agent(&st.py[r]), ld_agent(&st.pz[r]));
@@ -599,7 +610,7 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
             }
         }
         if (!fresh) { rs.fresh = false; rs.trips_base = seg * a->seg_trips; }
-        if (seg + 1u < a->segments) rs.max_trips = a->seg_trips;
+        if (SEG && seg + 1u < a->segments) rs.max_trips = a->seg_trips;
         tot.n_marched += fresh ? (unsigned)__popcll(ballot(marching)) : 0u;
     }
     const VolumeDev vol = load_arg(&a->vol);
@@ -617,7 +628,7 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
     {
         MarchArgsPtr b = march_args();
         const RayStateDev st = load_arg(&b->st);                // loaded again: not carried through the march in SGPRs
-        const bool fresh = seg == 0, last = seg + 1u >= b->segments;      // likewise
+        const bool fresh = !SEG || seg == 0, last = !SEG || seg + 1u >= b->segments;      // likewise
         const unsigned group = (unsigned)__builtin_amdgcn_readfirstlane((int)r) >> 6;
         if (last) {
             if (marching) {
@@ -646,8 +657,8 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
     tot.clk_sum += clk1 - clk0; tot.real_sum += real1 - real0;
 }
 
-template <int ALGO, int INTERP, bool SAVE, bool NOISE>
-__global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES) void march_kernel(MarchArgs) {
+template <int ALGO, int INTERP, bool SAVE, bool NOISE, bool SEG>
+__global__ __launch_bounds__(PHOTON_MARCH_BLOCK, (march_waves<INTERP, NOISE>())) void march_kernel(MarchArgs) {
     __shared__ f4 tiles[PHOTON_MARCH_BLOCK / 64][wave_lds_texels<INTERP>()];           // per wave: tile + brick, rows padded (device_volume_coop.hpp)
     f4 *const tile = tiles[threadIdx.x >> 6];
     const unsigned lane = threadIdx.x & 63u;
@@ -681,17 +692,25 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, INTERP == 1 ? PHOTON_MARCH_WAVE
             k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             const unsigned n_rays = march_args()->n_rays;
             const unsigned gq = march_queue_size((n_rays + 63u) / 64u, x, sub);
-            const unsigned n_seg = march_args()->segments;
+            const unsigned n_seg = SEG ? march_args()->segments : 1u;
             if (k >= gq * n_seg) break;                         // this queue is served (k < 2^26 / 64 * 255: no overflow)
-            const unsigned seg = n_seg > 1u ? k / gq : 0u;
-            march_group<ALGO, INTERP, SAVE, NOISE>(march_queue_group(k - seg * gq, x, sub), seg, n_rays, tile, tot);
+            const unsigned seg = SEG ? k / gq : 0u;
+            march_group<ALGO, INTERP, SAVE, NOISE, SEG>(march_queue_group(k - seg * gq, x, sub), seg, n_rays, tile, tot);
+            if ((tot.mc.samples | tot.mc.iterations) >> 31) {     // wave-uniform: the 32-bit wave totals go out before they can wrap
+                if (lane == 0) {
+                    unsigned long long *slot = counter_slot(march_args()->counters);
+                    atomicAdd(&slot[CNT_ITER], (unsigned long long)tot.mc.iterations);
+                    atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)tot.mc.samples);
+                }
+                tot.mc.iterations = tot.mc.samples = 0u;
+            }
         }
     }
 #else
     {                                                           // one-shot grid (A/B builds): one group per wave
         const unsigned n_rays = march_args()->n_rays;
         const unsigned group = xcd_remap(blockIdx.x, gridDim.x) * (PHOTON_MARCH_BLOCK / 64) + (threadIdx.x >> 6);
-        if (group < (n_rays + 63u) / 64u) march_group<ALGO, INTERP, SAVE, NOISE>(group, 0u, n_rays, tile, tot);
+        if (group < (n_rays + 63u) / 64u) march_group<ALGO, INTERP, SAVE, NOISE, false>(group, 0u, n_rays, tile, tot);
     }
 #endif
     if (tot.groups) {                                           // wave-uniform
@@ -946,13 +965,6 @@ struct photon_sources {                 // light-field sources generated in HBM 
 };
 
 struct PermEntry { long long begin = -1, end = -1; int *d_perm = nullptr; size_t capacity = 0; unsigned long long stamp = 0; };
-struct photon_sort_scratch {                // photon_sort.hip: keys / indices / radix-sort temporaries, grown on demand
-    unsigned *box = nullptr, *keys = nullptr;
-    int *idx = nullptr;
-    void *tmp = nullptr;
-    size_t capacity = 0, tmp_bytes = 0;
-};
-void photon_sort_scratch_free(photon_sort_scratch *scratch);
 
 struct photon_scene {
     SceneDev dev{};
@@ -960,7 +972,7 @@ struct photon_scene {
     RayStateDev ws{};                   // march -> sensor state, grown on demand
     size_t ws_rays = 0;
     unsigned long long *d_counters = nullptr;
-    unsigned *d_queue = nullptr;        // the march's work queues: 64 counters (8 XCDs x 8 sub-queues), a cache line apart
+    unsigned *d_queue = nullptr;        // the march's work queues: room for 64 counters a cache line apart, 8 XCDs x kSubQueues (4) in use
     int num_cus = 256;                  // compute units of the scene's device (size of the persistent march grid)
     unsigned *d_error = nullptr;        // march waves that gave a segment up (march_error_check)
     unsigned march_epoch = 0;           // tag of the last segmented march launch in ws.seg_flag
@@ -978,6 +990,7 @@ struct photon_scene {
     uint64_t win_rays = 0;
     uint32_t win_traces = 0;
     bool win_have_volume = false;
+    hipStream_t win_stream = nullptr;   // the stream the window was opened on: its traces must run there (the counters were zeroed there)
     int ray_order_mode = 2;             // 0 source-major, 1 lens-major, 2 auto (photon_scene_set_ray_order)
     bool skip_doomed = true;            // photon_scene_set_skip_doomed
     float lens_z = 0.f;                 // element 0's centre, for the auto rule
@@ -1086,7 +1099,7 @@ static bool parse_nrrd(const char *path, std::vector<float> &rho, int dims[3], d
 // =============================================================================================
 extern "C" {
 
-const char *photon_version(void) { return "photon-amd 0.1 (gfx950, HIP)"; }
+const char *photon_version(void) { return "photon-amd 0.4 (gfx950, HIP)"; }
 
 int photon_set_device(int device) {
     PH_CHECK(hipSetDevice(device));
@@ -1772,8 +1785,6 @@ static int end_accumulate(photon_scene *s, float *d_image, hipStream_t stream) {
 // a host sort cost a D2H of the coordinates, ~0.1 s of std::stable_sort and an H2D per call).  The permutation
 // covers exactly the launched range, so [src_begin, src_end) always counts sources in the CALLER's order,
 // whatever order the lanes then use; it is kept for the next launch of the same range.
-int photon_morton_order(const float *d_x, const float *d_y, int first, long long n, int *d_perm_out, hipStream_t stream,
-                        photon_sort_scratch *scratch);
 
 // The permutation of a launched range is kept (a few ranges: a job's chunks, a caller alternating shards), and the sort's
 // scratch lives in the scene: a lens-major launch of a range seen before costs nothing, a new range costs the sort's
@@ -1919,18 +1930,25 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
             bool forced = s->march_segments > 1;                // an explicit count segments launches of any size (tests)
             const int want = s->march_segments >= 0 ? s->march_segments : march_segments_default(&forced);
             if (want > 1 && (forced || groups >= slots + slots / 4)) {
-                // equal trip counts, and (unless the count is forced) at least 16 trips per segment: the state round trip and
-                // the refetch of the parked tile are then below a per cent of the segment (a 48^3 volume: 3 segments, not 8)
+                // How many: a segment should last ~0.25 ms -- the hand-off costs a few microseconds (flag poll, state round trip,
+                // tile refetch), and measured on C3 with 8 segments whatever the kernel: RK4 tricubic (1.9 ms per group) 59.06 ->
+                // 58.26 ms, RK4 trilinear (0.63 ms) 19.9 -> 20.8, Euler trilinear (0.24 ms) 7.5 -> 10.1.  Work of a group in
+                // units of one trilinear sample per texel of depth: x3 for RK4's three samples, x3 for the 64-tap sampler;
+                // 288 units per segment is RK4 tricubic through 256 texels in 8 pieces.
                 const unsigned depth = (unsigned)std::max(vol->dev.nx, std::max(vol->dev.ny, vol->dev.nz));
                 segments = (unsigned)std::min(want, 64);
-                if (!forced) segments = std::max(1u, std::min(segments, depth / 16u));
+                if (!forced) {
+                    const unsigned units = depth * (algorithm == 2 ? 3u : 1u) * (interp == 2 ? 3u : 1u);
+                    segments = std::max(1u, std::min(segments, (units + 144u) / 288u));
+                }
                 seg_trips = std::max(4u, (depth + segments - 1) / segments);
                 if (segments > 1) { rc = ensure_resume_state(s, interp == 1, stream); if (rc) return rc; }
             }
         }
         const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue, profile,
                               segments, seg_trips, s->march_epoch, s->d_error};
-#define PH_MARCH(A, I, S, N) hipLaunchKernelGGL((march_kernel<A, I, S, N>), mgrid, mblock, 0, stream, margs)
+#define PH_MARCH(A, I, S, N) do { if (!S && !N && segments > 1) hipLaunchKernelGGL((march_kernel<A, I, false, false, true>), mgrid, mblock, 0, stream, margs); \
+                                  else hipLaunchKernelGGL((march_kernel<A, I, S, N, false>), mgrid, mblock, 0, stream, margs); } while (0)
         if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
         else if (algorithm != 1 && algorithm != 2) hipLaunchKernelGGL((march_extra_kernel<0>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
@@ -1965,6 +1983,8 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     return 0;
 }
 
+constexpr unsigned kWindowMaxTraces = 1u << 16;        // traces per statistics window (each keeps a few HIP events alive)
+
 // An event of the open statistics window (created on first use, kept for the next window).
 static int window_event(photon_scene *s, size_t *index_out) {
     if (s->win_used == s->win_events.size()) {
@@ -1992,15 +2012,15 @@ static int trace_accumulate(photon_scene *scene, const photon_volume *vol, int r
         const long long e = std::min<long long>(src_end, b + max_sources);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed == 1 && vol) { e0 = scene->ev[1]; e1 = scene->ev[2]; }
+        size_t i0 = 0, i1 = 0;
         if (timed == 2 && vol) {
-            size_t i0, i1;
             { const int rc = window_event(scene, &i0); if (rc) return rc; }
             { const int rc = window_event(scene, &i1); if (rc) return rc; }
             e0 = scene->win_events[i0]; e1 = scene->win_events[i1];
-            scene->win_march.emplace_back(i0, i1);
         }
         const int rc = launch_chunk(scene, vol, ray_tracing_algorithm, b, e, no_dump, stream, e0, e1);
         if (rc) return rc;
+        if (timed == 2 && vol) scene->win_march.emplace_back(i0, i1);      // only pairs whose events were recorded
         if (timed == 1 && vol) {
             PH_CHECK(hipEventSynchronize(scene->ev[2]));
             float ms = 0.f;
@@ -2137,6 +2157,14 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
                         "pass stats = NULL and read them with photon_scene_stats_end\n");
         return 1;
     }
+    if (scene->win_open && (hipStream_t)stream_p != scene->win_stream) {
+        fprintf(stderr, "photon: photon_trace: a statistics window is open on another stream (its counters were zeroed there)\n");
+        return 1;
+    }
+    if (scene->win_open && scene->win_traces >= kWindowMaxTraces) {
+        fprintf(stderr, "photon: photon_trace: more than %u traces in one statistics window; close it with photon_scene_stats_end\n", kWindowMaxTraces);
+        return 1;
+    }
     return guarded("photon_trace", [&]() -> int {
         hipStream_t stream = (hipStream_t)stream_p;
         const unsigned rps = (unsigned)scene->dev.rays_per_source;
@@ -2190,6 +2218,7 @@ extern "C" int photon_scene_stats_begin(photon_scene_t *scene, void *stream_p) {
         scene->win_rays = 0;
         scene->win_traces = 0;
         scene->win_have_volume = false;
+        scene->win_stream = stream;
         scene->win_open = true;
         return 0;
     });

@@ -9,6 +9,7 @@
 // deterministic) -- with no host round trip of the coordinates.  Speed only: the image is a sum over sources.
 //
 // Own translation unit: the sort's templates do not ride in the march kernels' compile.
+#include "photon_sort.hpp"
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -72,15 +73,6 @@ __global__ void init_box_kernel(unsigned *box) {
 
 }  // namespace
 
-// Scratch of the sort, owned by the caller (the scene) and grown on demand: with it a sort allocates nothing and never
-// waits for the host -- photon_trace stays asynchronous on its stream when a lens-major launch has to order a new range.
-struct photon_sort_scratch {
-    unsigned *box = nullptr, *keys = nullptr;       // keys: 2 x capacity (in, out)
-    int *idx = nullptr;
-    void *tmp = nullptr;
-    size_t capacity = 0, tmp_bytes = 0;
-};
-
 void photon_sort_scratch_free(photon_sort_scratch *s) {
     if (!s) return;
     if (s->box) (void)hipFree(s->box);
@@ -90,9 +82,6 @@ void photon_sort_scratch_free(photon_sort_scratch *s) {
     *s = photon_sort_scratch{};
 }
 
-// perm_out[k] (device, n entries) = index, in the CALLER's source numbering, of the k-th source of
-// [first, first + n) in Morton order.  x, y: device pointers to the whole source arrays.  Asynchronous on
-// `stream`; allocates only when the scratch has to grow.  Returns 0 or a HIP error code.
 int photon_morton_order(const float *d_x, const float *d_y, int first, long long n, int *d_perm_out, hipStream_t stream,
                         photon_sort_scratch *sc) {
     if (n <= 0) return 0;

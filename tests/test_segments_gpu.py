@@ -87,10 +87,13 @@ def test_segment_counters_and_uneven_load(photon, volume_file, interp):
     vol.free()
 
 
-def test_large_launch_is_segmented_by_default(photon, volume_file):
-    """2e6 rays = 31250 groups, six chip fills: the library segments on its own (8 pieces); same counters, same image as
-    whole marches, and the launch's drain -- the average time a wave slot stands empty at its end -- shrinks."""
+def test_large_launch_is_segmented_by_default(photon, workdir):
+    """2e6 rays = 31250 groups, six chip fills, through 128^3 (tricubic RK4: ~1 ms per group): the library segments on its
+    own (4 pieces of ~0.25 ms); same counters, same image as whole marches, and the launch's drain -- the average time a
+    wave slot stands empty at its end -- shrinks."""
     import torch
+    rho, sp, org = scenes.bos_volume(128)
+    volume_file = scenes.write_nrrd(os.path.join(workdir, "seg128.nrrd"), rho, sp, org)
     call = scenes.bos_scene(n_dots=40, points_per_dot=100, rays_per_source=500, density_grad_filename=volume_file)
     scene = photon.scene_create(call)
     vol = photon.volume_load_nrrd(volume_file, 2)

@@ -10,15 +10,18 @@ wl=("$@"); [ ${#wl[@]} -eq 0 ] && wl=(cubic linear euler_cubic euler_linear c5)
 out=$ROOT/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="$ROOT/bench.py --steps 3 --warmup 1 --cpu-sample-rays 0 --no-traffic"
+B="$ROOT/bench.py --steps 3 --warmup 1 --cpu-sample-rays 0 --no-traffic --no-other-configs --no-profile"
+# the strong-scaling tail is a 8 ms launch: three of them say nothing about the clock the chip settles at (round 3's
+# tail profile read 1978 MHz from 40 ms of GPU work) -- 100 steps for its kernel trace, 20 for the counter passes
+BT="$ROOT/bench.py --warmup 5 --cpu-sample-rays 0 --no-traffic --no-other-configs --no-profile --dots 25"
 for w in "${wl[@]}"; do
-  pmc=1
+  pmc=1; pcmd=
   case $w in
     cubic) cmd="$B" ;;
     linear) cmd="$B --interp linear" ;;
     euler_cubic) cmd="$B --algorithm 1" ;;
     euler_linear) cmd="$B --algorithm 1 --interp linear" ;;
-    tail) cmd="$B --dots 25" ;;
+    tail) cmd="$BT --steps 100"; pcmd="$BT --steps 20" ;;
     c4) cmd="$B --volume 512 --dots 2000"; pmc=0 ;;
     c5) cmd="$ROOT/tools/c5_full.py 0.25" ;;
     *) echo "unknown workload $w"; exit 1 ;;
@@ -27,6 +30,7 @@ for w in "${wl[@]}"; do
   echo "== $w: $cmd"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$d/stats" -o s -- python3 $cmd > "$d/stats.log" 2>&1)
   [ $pmc = 1 ] || continue
+  [ -n "$pcmd" ] && cmd=$pcmd
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
     n=$(echo $set | cut -d' ' -f1)
     (cd /tmp && rocprofv3 --pmc $set --output-format csv -d "$d/pmc_$n" -o p -- python3 $cmd > "$d/pmc_$n.log" 2>&1)
