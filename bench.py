@@ -63,7 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--volume", type=int, default=256, help="grid points per axis of the density volume")
     ap.add_argument("--dots", type=int, default=200, help="BOS dots of the job (strong) / per GPU (weak); x100 sources x500 rays")
     ap.add_argument("--rays-per-source", type=int, default=500)
-    ap.add_argument("--cpu-sample-rays", type=int, default=1000000, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-rays", type=int, default=4000000,
+                    help="size of the CPU-baseline sample (0 = skip): half of it is the all-cores leg, ~10 s on 16 threads")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--check", action="store_true", help="also verify a slice of the image against the oracle")
     ap.add_argument("--clock-trace", type=int, default=0, metavar="W",
@@ -157,6 +158,7 @@ def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source
     o = Oracle()
     cores = cpu_budget()
     o.set_num_threads(cores)
+    omp_default = o.num_threads()
 
     def loop_rate(n_src, threads):
         o.set_num_threads(threads)
@@ -191,6 +193,8 @@ def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source
         legs[name] = {"rays": c.num_rays, "ms": round(d * 1e3, 2), "Mrays_per_s": round(c.num_rays / d * 1e-6, 3), "runs": 5}
     rays = n_src * rays_per_source
     return {"value": rate, "unit": "Mrays/s", "cores": o.num_threads(), "kind": "port", "cpu_model": cpu_model(),
+            "threads": {"used": omp_default, "affinity": len(os.sched_getaffinity(0)), "cgroup_budget": cores,
+                        "speedup_over_one_thread": round(rate / rate_one, 2) if rate_one > 0 else None},
             "sample": f"{rays} rays ({n_src} sources x {rays_per_source}) of the same scene and volume, ray loop only "
                       f"(volume prebuilt), {dt:.1f} s; extrapolates linearly to the 1e7-ray job ({1e7 / (rate * 1e6):.0f} s)",
             "one_thread": {"value": round(rate_one, 5), "unit": "Mrays/s", "sample": f"{n_one * rays_per_source} rays, {dt_one:.1f} s"},
@@ -304,7 +308,8 @@ def gpu_other_configs(lib, torch, workdir, with_c4):
     resident like the headline: C2 (PIV, Mie, thick lens, 4-pixel splat, no volume), C3 with the trilinear sampler (the one
     the reference executes, parallel_ray_tracing.cu:3330), C5 at a quarter of its size on one GPU (the incoherent launch:
     full-aperture cones, lens-major order, doomed rays skipped), one GPU's eighth of C3 (the strong-scaling tail at N = 8)
-    and, on request, C4 whole.  Three traces each after one warm-up, statistics over the three."""
+    and, on request, C4 whole.  Each leg runs for a few tenths of a second after one warm-up (3 to 200 traces: a handful of
+    short launches reads 5 % low, the clock has not settled), statistics over those traces."""
     from photon_amd import scenes
     legs = {}
 
@@ -332,14 +337,14 @@ def gpu_other_configs(lib, torch, workdir, with_c4):
         if vol is not None:
             vol.free()
 
-    run("C2", scenes.config("C2"), 0, "PIV, 100 particles x 1e4 rays, Mie, thick lens, 4-pixel splat, no volume (one fused kernel)")
+    run("C2", scenes.config("C2"), 0, "PIV, 100 particles x 1e4 rays, Mie, thick lens, 4-pixel splat, no volume (one fused kernel)", reps=200)
     run("C3_trilinear", scenes.config("C3", workdir), 1,
-        "the headline job with the trilinear sampler and the texture unit's 8-bit weights (the reference's executed path)")
+        "the headline job with the trilinear sampler and the texture unit's 8-bit weights (the reference's executed path)", reps=10)
     run("C3_eighth", scenes.bos_scene(n_dots=25, density_grad_filename=os.path.join(workdir, "bos_256.nrrd")), 2,
-        "one GPU's eighth of the headline job (1.25e6 rays, tricubic RK4): the strong-scaling tail at N = 8")
+        "one GPU's eighth of the headline job (1.25e6 rays, tricubic RK4): the strong-scaling tail at N = 8", reps=40)
     run("C5_quarter", scenes.config("C5", workdir, scale=0.25), 2,
         "Mie PIV through the volume at 1/4 size: 2.5e5 polydisperse particles x 40 rays, 161^3 tricubic RK4, full-aperture cones "
-        "(lens-major order, doomed rays skipped)")
+        "(lens-major order, doomed rays skipped)", reps=8)
     if with_c4:
         run("C4", scenes.config("C4", workdir), 2, "C4 whole on one GPU: 2e5 sources x 500 = 1e8 rays, 512^3, tricubic RK4 (two launches)", reps=1)
     return legs
@@ -680,19 +685,19 @@ def main():
                                 "what": "reduced image of all ranks vs the oracle's render of the whole job"}
         elif do_check:
             out["check"] = check_against_oracle(lib, make_call, vol_path, interp)
-            if world > 1:
-                # the REDUCED image of the last timed step (all ranks' shards, summed by RCCL onto this rank) against the same
-                # job rendered by this GPU alone: sharding, shard-only uploads and the reduce, end to end
-                single = torch.zeros_like(image)
-                for seed in ([1] if strong else [1 + r for r in range(world)]):
-                    whole = lib.scene_create(make_call(seed=seed))
-                    whole.trace(single.data_ptr(), volume, args.algorithm, stream=stream)      # accumulates
-                    torch.cuda.synchronize()
-                    whole.free()
-                diff = (image.double() - single.double()).norm() / single.double().norm()
-                out["check"]["sharded_vs_single_gpu_rel_l2"] = float(diff.item())
-                out["check"]["what"] = ("rel_l2: 40 sources through start_ray_tracing vs the CPU oracle; sharded_vs_single_gpu_rel_l2: the "
-                                        "image all ranks reduced onto rank 0 vs the whole job rendered by rank 0's GPU alone")
+        if world > 1 and (do_check or args.rehearse):
+            # the REDUCED image of the last timed step (all ranks' shards, summed onto this rank: RCCL, or gloo in a rehearsal)
+            # against the same job rendered by this GPU alone: sharding, shard-only uploads and the reduce, end to end
+            single = torch.zeros_like(image)
+            for seed in ([1] if strong else [1 + r for r in range(world)]):
+                whole = lib.scene_create(make_call(seed=seed))
+                whole.trace(single.data_ptr(), volume, args.algorithm, stream=stream)      # accumulates
+                torch.cuda.synchronize()
+                whole.free()
+            diff = (image.double() - single.double()).norm() / single.double().norm()
+            out.setdefault("check", {})["sharded_vs_single_gpu_rel_l2"] = float(diff.item())
+            out["check"]["what"] = ("rel_l2: this library vs the CPU oracle (40 sources through start_ray_tracing; in a rehearsal the whole job); "
+                                    "sharded_vs_single_gpu_rel_l2: the image all ranks reduced onto rank 0 vs the whole job rendered by rank 0's GPU alone")
         print(json.dumps(out), flush=True)
     scene.free()
     volume.free()

@@ -22,6 +22,8 @@ struct VolumeDev {
     int interpolation;          // 1 trilinear, 2 tricubic
     float weight_scale;         // trilinear weights: 0 = exact f32, 256 = NVIDIA texture-unit emulation (8 fractional bits)
     float weight_inv;           // 1 / weight_scale (a power of two: exact), 0 when weight_scale is 0
+    int weight_fast;            // the grid is small enough for the one-instruction-shorter form of the fixed-point weights
+                                // (tex3d_linear_coop: largest n x weight_scale <= 2^21)
     const f4 *texels;           // grad n (xyz), n-1 (w)   [nz][ny][nx]
     const f4 *coeffs;           // B-spline coefficients    [nz][ny][nx] (interpolation == 2)
 };

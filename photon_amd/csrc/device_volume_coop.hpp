@@ -36,11 +36,18 @@ namespace photon {
 #ifndef PHOTON_TILE_REUSE
 #define PHOTON_TILE_REUSE 1
 #endif
+// Two register-pressure measures for the trilinear kernels, measured in round 4 on C3 (same box, Mrays/s; round 3's library
+// 465-467 RK4 / 1101 Euler): val_prev in a per-lane LDS slot -- RK4 461 with, 463-468 without; Euler 1072 / 1079: OFF;
+// the tile's lane offsets recomputed per fetch instead of hoisted (and spilled) -- RK4 468 with, 453 without; Euler 1079
+// with, 1095 without (a fetch every other sample weighs more where a sample is a third of the work): ON for RK4 only.
 #ifndef PHOTON_PREV_STASH
-#define PHOTON_PREV_STASH 1         // the trilinear branches' val_prev in a per-lane LDS slot (1) or in four VGPRs (0)
+#define PHOTON_PREV_STASH 0         // the trilinear branches' val_prev in a per-lane LDS slot (1) or in four VGPRs (0)
+#endif
+#ifndef PHOTON_WEIGHT_FAST
+#define PHOTON_WEIGHT_FAST 1        // the shorter form of the fixed-point trilinear weights where the grid allows it (tex3d_linear_coop)
 #endif
 #ifndef PHOTON_TILE_LANE_PIN
-#define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch (1) or left to the compiler to hoist (0)
+#define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch in the RK4 kernels (1) or left to the compiler (0)
 #endif
 // Row pitch of the brick in LDS, in texels.  The brick is 8 texels wide; with a pitch of 8 the 16-byte reads of lanes
 // whose blocks sit two rows apart land on the same four banks (a ds_read_b128 serves 16 lanes per LDS cycle from 64
@@ -55,7 +62,7 @@ constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels betwee
 // per wave: the tile (64 texels reserved; trilinear uses 8) + the brick: 8x8x4 texels for the tricubic sampler, 8x8x2 for
 // the trilinear one -- 7 KiB against 4 KiB, i.e. at most 5 against 10 workgroups of four waves in a CU's 160 KiB
 // -- and, for the trilinear kernels, one more 16-byte slot per lane behind the brick: the last value the lane sampled (PrevStash)
-template <int INTERP> constexpr int wave_lds_texels() { return 64 + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 ? 64 : 0); }
+template <int INTERP> constexpr int wave_lds_texels() { return 64 + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 && PHOTON_PREV_STASH ? 64 : 0); }
 constexpr int kPrevStashOffset = 64 + 2 * kBrickSlab;           // texel slot of lane 0's stash in a trilinear wave's LDS area
 constexpr int kWaveLdsTexels = wave_lds_texels<2>();
 
@@ -437,7 +444,7 @@ __device__ __forceinline__ float pair_swap(float v) {
 
 // QUANT: the volume uses the texture unit's fixed-point weights (v.weight_scale > 0; the march kernels branch ONCE on
 // it -- as a run-time select per weight it cost three v_cndmask per sample).
-template <bool QUANT>
+template <bool QUANT, bool PIN = false>
 __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need,
                                                 float x, float y, float z, Parked &parked) {
     f4 *const brick = blk + 64;                                 // 8x8x2 texels around the leader for incoherent waves
@@ -445,9 +452,20 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
     float a = xb - fi, b = yb - fj, c = zb - fk;
     if (QUANT) {                                                // texture-unit weights (8 fractional bits)
-        a = floorf(fmaf(a, v.weight_scale, 0.5f)) * v.weight_inv;       // quant_weight() with the scale known positive
-        b = floorf(fmaf(b, v.weight_scale, 0.5f)) * v.weight_inv;
-        c = floorf(fmaf(c, v.weight_scale, 0.5f)) * v.weight_inv;
+        if (PHOTON_WEIGHT_FAST && v.weight_fast) {              // wave-uniform
+            // round(frac(xb) S) / S, ties up, from xb itself: K = floor(xb S + 1/2), weight = K / S - floor(xb).  With S = 2^bits,
+            // xb = fi + a exactly (a = xb - fi is exact) and xb S + 1/2 exact in f32 while xb S < 2^22 -- i.e. for every
+            // sampled coordinate of a grid with n S <= 2^21, what weight_fast says -- floor(xb S + 1/2) = fi S + floor(a S + 1/2);
+            // K / S - fi is a multiple of 1/S in [0, 1], so the fused multiply-add returns it exactly: the bits of the
+            // two-step form below (and of the CPU checker's), one instruction fewer per axis.
+            a = fmaf(floorf(fmaf(xb, v.weight_scale, 0.5f)), v.weight_inv, -fi);
+            b = fmaf(floorf(fmaf(yb, v.weight_scale, 0.5f)), v.weight_inv, -fj);
+            c = fmaf(floorf(fmaf(zb, v.weight_scale, 0.5f)), v.weight_inv, -fk);
+        } else {
+            a = floorf(fmaf(a, v.weight_scale, 0.5f)) * v.weight_inv;       // quant_weight() with the scale known positive
+            b = floorf(fmaf(b, v.weight_scale, 0.5f)) * v.weight_inv;
+            c = floorf(fmaf(c, v.weight_scale, 0.5f)) * v.weight_inv;
+        }
     }
     const int lane = threadIdx.x & 63;
     if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
@@ -463,10 +481,8 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 8) {
                     int l = lane;
-#if PHOTON_TILE_LANE_PIN
-                    asm volatile("" : "+v"(l));                 // keep the tile's lane offsets out of the march loop's live registers:
-                                                                // hoisted as loop invariants they were spilled, and every fetch reloaded them from scratch
-#endif
+                    if (PIN && PHOTON_TILE_LANE_PIN) asm volatile("" : "+v"(l));       // keep the tile's lane offsets out of the march loop's live
+                                                                // registers: hoisted as loop invariants they were spilled, every fetch reloading them
                     const int ci = (int)__int_as_float(ld.i), cj = (int)__int_as_float(ld.j), ck = (int)__int_as_float(ld.k);
                     const int tx = clampi(ci + (l & 1), 0, v.nx - 1), ty = clampi(cj + ((l >> 1) & 1), 0, v.ny - 1),
                               tz = clampi(ck + ((l >> 2) & 1), 0, v.nz - 1);
@@ -617,10 +633,10 @@ struct PrevVal {                                                // A/B form: the
 #endif
 
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
-template <int INTERP, bool QUANT, class CNT>
+template <int INTERP, bool QUANT, class CNT, bool PIN = false>
 __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need, f3 lookup,
                                           const PrevVal &prev, float data_min, CNT &mc, Parked &parked) {
-    f4 val = INTERP == 1 ? tex3d_linear_coop<QUANT>(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked)
+    f4 val = INTERP == 1 ? tex3d_linear_coop<QUANT, PIN>(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked)
                          : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked);
     count_samples(mc, need);
     if (INTERP == 1) {
@@ -630,7 +646,7 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
             const f4 val_prev = prev.get();                     // the lane's last sampled value (parked in LDS)
             const unsigned long long repair = low & ballot(val_prev.w == 0);
             if (repair != 0) {
-                const f4 t = tex3d_linear_coop<QUANT>(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
+                const f4 t = tex3d_linear_coop<QUANT, PIN>(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
                 count_samples(mc, repair);
                 if (lane_of(repair)) val = f4{t.x, t.y, t.z, ambient - 1};
             }
@@ -712,7 +728,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
             go = alive & access;
             spin = alive & ~access;                             // the reference's `continue`: step forward, retry next trip
         }
-        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
+        f4 val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
         if (INTERP == 2) {                                      // .h:1220-1227
             const unsigned long long low = go & ballot(val.w < u.data_min);
             spin |= low;
@@ -739,7 +755,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         unsigned long long in = inside_mask(spos, u);           // .h:1094-1101: outside = `break`, nothing committed
         active &= ~go | in;
         go &= in;
-        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
+        val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
         const float n_b = val.w + 1;
         const f3 B = delta_t * mk3(n_b * val.x, n_b * val.y, n_b * val.z);
         spos = rpos + delta_t * T_n + (0.5f * delta_t) * B;                     // .h:1131
@@ -749,7 +765,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         in = inside_mask(spos, u);                              // .h:1135-1141
         active &= ~go | in;
         go &= in;
-        val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
+        val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
         const float n_c = val.w + 1;
         const f3 C = delta_t * mk3(n_c * val.x, n_c * val.y, n_c * val.z);
         if (INTERP == 1) prev.set(f4{val.x, val.y, val.z, n_c - 1});

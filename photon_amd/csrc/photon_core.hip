@@ -1305,6 +1305,7 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
     d.interpolation = interpolation;
     d.weight_inv = 1.0f / 256.f;
     d.weight_scale = 256.f;             // trilinear weights as the reference's texture unit holds them (photon_volume_set_weight_bits)
+    d.weight_fast = (double)std::max(nx, std::max(ny, nz)) * 256.0 <= 2097152.0;
     d.texels = v->d_texels;
     d.coeffs = v->d_coeffs;
     photon_volume_info_t &info = v->info;
@@ -1339,6 +1340,7 @@ int photon_volume_set_weight_bits(photon_volume_t *vol, int bits) {
     if (!vol || bits < 0 || bits > 23) return 1;
     vol->dev.weight_scale = bits ? (float)(1 << bits) : 0.f;
     vol->dev.weight_inv = bits ? 1.0f / (float)(1 << bits) : 0.f;
+    vol->dev.weight_fast = bits && (double)std::max(vol->dev.nx, std::max(vol->dev.ny, vol->dev.nz)) * (double)(1 << bits) <= 2097152.0;
     return 0;
 }
 

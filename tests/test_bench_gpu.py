@@ -75,5 +75,7 @@ def test_bench_rehearsal_three_ranks_on_one_gpu(photon):
     assert d["roofline"]["texel_rate_vs_lds"]["rays_per_launch"] == 2 * 100 * 500      # rank 0's third of the sources
     assert d["rays_on_sensor"] == 6 * 100 * 500
     assert d["check"]["sources"] == 600 and d["check"]["rel_l2"] <= 1e-5
+    assert d["check"]["sharded_vs_single_gpu_rel_l2"] <= 1e-6                    # what every real N > 1 line carries too
     w = _bench("--gpus", "2", "--rehearse", "--scaling", "weak", "--cpu-sample-rays", "0", "--no-traffic")
     assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["config"]["rays_total"] == 2 * 6 * 100 * 500
+    assert w["check"]["sharded_vs_single_gpu_rel_l2"] <= 1e-6                    # two different scenes, summed
