@@ -44,8 +44,9 @@ namespace photon {
 #define PHOTON_PREV_STASH 0         // the trilinear branches' val_prev in a per-lane LDS slot (1) or in four VGPRs (0)
 #endif
 #ifndef PHOTON_WEIGHT_FAST
-#define PHOTON_WEIGHT_FAST 1        // the shorter form of the fixed-point trilinear weights where the grid allows it (tex3d_linear_coop)
-#endif
+#define PHOTON_WEIGHT_FAST 0        // a one-instruction-shorter exact form of the fixed-point trilinear weights where the grid allows it
+#endif                              // (tex3d_linear_coop): bit-identical, and SLOWER -- RK4 469 -> 459, Euler 1092 -> 1080 Mrays/s on C3: the
+                                    // wave-uniform branch costs these register-bound kernels more than three instructions save.  Off.
 #ifndef PHOTON_TILE_LANE_PIN
 #define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch in the RK4 kernels (1) or left to the compiler (0)
 #endif

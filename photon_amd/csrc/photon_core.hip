@@ -93,6 +93,88 @@ static int guarded(const char *what, F &&body) {
 }
 
 // =============================================================================================
+// a cache of freed device blocks
+// =============================================================================================
+// photon's unchanged Python builds everything anew for every start_ray_tracing call: per call ~25 hipMalloc / hipFree
+// pairs, among them the ray-state workspace (320 MB for the 1e7-ray job) -- measured, the frees alone take 0.8-1.3 ms of a
+// call (PHOTON_VERBOSE), 10 % of one GPU's eighth of the headline job, most of a small PIV frame.  Scene-lifetime blocks are
+// therefore handed back to this cache instead of the runtime and the next call of the same shape takes them from it
+// (exact size match, per device); the cache holds at most PHOTON_POOL_MAX_MB (default 4096; 0 = off), evicting its largest
+// blocks first; photon_trim_caches() empties it.  Recycled memory is not zeroed -- neither is hipMalloc'd memory: every
+// buffer that needs a defined start is cleared where it is allocated or used.
+namespace {
+struct PoolKey {
+    int device; size_t bytes;
+    bool operator<(const PoolKey &o) const { return device != o.device ? device < o.device : bytes < o.bytes; }
+};
+struct DevicePool {
+    std::mutex lock;
+    std::multimap<PoolKey, void *> idle;
+    std::map<void *, PoolKey> live;
+    size_t idle_bytes = 0;
+};
+DevicePool &device_pool() { static DevicePool *p = new DevicePool; return *p; }      // never destroyed: the runtime may be gone by then
+size_t pool_cap_bytes() {
+    static const size_t cap = [] { const char *e = getenv("PHOTON_POOL_MAX_MB"); return (size_t)(e ? strtoull(e, nullptr, 10) : 4096ull) << 20; }();
+    return cap;
+}
+void pool_trim(size_t keep_bytes) {                              // caller holds no lock
+    DevicePool &p = device_pool();
+    std::vector<void *> victims;
+    {
+        std::lock_guard<std::mutex> g(p.lock);
+        while (p.idle_bytes > keep_bytes && !p.idle.empty()) {
+            auto big = p.idle.begin();
+            for (auto it = p.idle.begin(); it != p.idle.end(); ++it) if (it->first.bytes > big->first.bytes) big = it;
+            p.idle_bytes -= big->first.bytes;
+            victims.push_back(big->second);
+            p.idle.erase(big);
+        }
+    }
+    for (void *v : victims) (void)hipFree(v);
+}
+hipError_t pool_malloc(void **out, size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    DevicePool &p = device_pool();
+    {
+        std::lock_guard<std::mutex> g(p.lock);
+        auto it = p.idle.find(PoolKey{device, bytes});
+        if (it != p.idle.end()) {
+            *out = it->second;
+            p.idle.erase(it);
+            p.idle_bytes -= bytes;
+            p.live[*out] = PoolKey{device, bytes};
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); pool_trim(0); e = hipMalloc(out, bytes); }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(p.lock); p.live[*out] = PoolKey{device, bytes}; }
+    return e;
+}
+void pool_free(void *ptr) {
+    if (!ptr) return;
+    DevicePool &p = device_pool();
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> g(p.lock);
+        auto it = p.live.find(ptr);
+        if (it != p.live.end()) {
+            const PoolKey k = it->second;
+            p.live.erase(it);
+            if (k.bytes <= pool_cap_bytes()) { p.idle.emplace(k, ptr); p.idle_bytes += k.bytes; keep = true; }
+        }
+    }
+    if (!keep) { (void)hipFree(ptr); return; }
+    if (device_pool().idle_bytes > pool_cap_bytes()) pool_trim(pool_cap_bytes());
+}
+}  // namespace
+
+extern "C" void photon_trim_caches(void) { pool_trim(0); }
+
+// =============================================================================================
 // device-side aggregates
 // =============================================================================================
 struct RayStateDev {                // SoA ray state between the march and the sensor stage
@@ -1005,7 +1087,7 @@ template <typename T>
 static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
     T *d = nullptr;
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    PH_CHECK(hipMalloc((void **)&d, bytes));
+    PH_CHECK(pool_malloc((void **)&d, bytes));
     s->allocs.push_back(d);
     if (n) PH_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
     *dev_out = d;
@@ -1015,7 +1097,7 @@ static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
 template <typename T>
 static int copy_device(photon_scene *s, const T *dev_src, size_t n, const T **dev_out) {
     T *d = nullptr;
-    PH_CHECK(hipMalloc((void **)&d, std::max<size_t>(n, 1) * sizeof(T)));
+    PH_CHECK(pool_malloc((void **)&d, std::max<size_t>(n, 1) * sizeof(T)));
     s->allocs.push_back(d);
     if (n) PH_CHECK(hipMemcpy(d, dev_src, n * sizeof(T), hipMemcpyDeviceToDevice));
     *dev_out = d;
@@ -1405,16 +1487,16 @@ int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorit
 
 void photon_scene_free(photon_scene_t *s) {
     if (!s) return;
-    for (void *p : s->allocs) (void)hipFree(p);
-    if (s->ws.px) (void)hipFree(s->ws.px);
-    if (s->ws.radiance) (void)hipFree(s->ws.radiance);
+    for (void *p : s->allocs) pool_free(p);
+    pool_free(s->ws.px);
+    pool_free(s->ws.radiance);
     free_resume_state(s);
-    if (s->d_counters) (void)hipFree(s->d_counters);
-    if (s->d_queue) (void)hipFree(s->d_queue);
-    if (s->d_profile) (void)hipFree(s->d_profile);
-    if (s->d_error) (void)hipFree(s->d_error);
-    if (s->d_acc) (void)hipFree(s->d_acc);
-    for (auto &p : s->perms) if (p.d_perm) (void)hipFree(p.d_perm);
+    pool_free(s->d_counters);
+    pool_free(s->d_queue);
+    pool_free(s->d_profile);
+    pool_free(s->d_error);
+    pool_free(s->d_acc);
+    for (auto &p : s->perms) pool_free(p.d_perm);
     photon_sort_scratch_free(&s->sort_scratch);
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : s->win_events) if (e) (void)hipEventDestroy(e);
@@ -1659,13 +1741,13 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         fprintf(stderr, "photon: sensor needs at least one pixel\n");
         return bail(1);
     }
-    hipError_t e = hipMalloc((void **)&s->d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long));
+    hipError_t e = pool_malloc((void **)&s->d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
-    e = hipMalloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
+    e = pool_malloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
-    e = hipMalloc((void **)&s->d_queue, kQueues * kQueueStride * sizeof(unsigned));
+    e = pool_malloc((void **)&s->d_queue, kQueues * kQueueStride * sizeof(unsigned));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
-    e = hipMalloc((void **)&s->d_error, sizeof(unsigned));
+    e = pool_malloc((void **)&s->d_error, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(s->d_error, 0, sizeof(unsigned));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     {
@@ -1727,22 +1809,22 @@ int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {
 static const unsigned kMaxRaysPerLaunch = 1u << 26;
 
 static void free_resume_state(photon_scene *s) {
-    if (s->ws.ctr) { (void)hipFree(s->ws.ctr); s->ws.ctr = nullptr; }
-    if (s->ws.vprev) { (void)hipFree(s->ws.vprev); s->ws.vprev = nullptr; }
+    if (s->ws.ctr) { pool_free(s->ws.ctr); s->ws.ctr = nullptr; }
+    if (s->ws.vprev) { pool_free(s->ws.vprev); s->ws.vprev = nullptr; }
     s->ws.spins = nullptr; s->ws.seg_flag = nullptr;
 }
 
 static int ensure_workspace(photon_scene *s, size_t rays) {
     if (s->ws_rays >= rays) return 0;
-    if (s->ws.px) { (void)hipFree(s->ws.px); s->ws.px = nullptr; }
-    if (s->ws.radiance) { (void)hipFree(s->ws.radiance); s->ws.radiance = nullptr; }
+    if (s->ws.px) { pool_free(s->ws.px); s->ws.px = nullptr; }
+    if (s->ws.radiance) { pool_free(s->ws.radiance); s->ws.radiance = nullptr; }
     free_resume_state(s);
     s->ws_rays = 0;
     float *f = nullptr;
-    PH_CHECK(hipMalloc((void **)&f, rays * 6 * sizeof(float)));
+    PH_CHECK(pool_malloc((void **)&f, rays * 6 * sizeof(float)));
     s->ws.px = f; s->ws.py = f + rays; s->ws.pz = f + 2 * rays;
     s->ws.dx = f + 3 * rays; s->ws.dy = f + 4 * rays; s->ws.dz = f + 5 * rays;
-    PH_CHECK(hipMalloc((void **)&s->ws.radiance, rays * sizeof(double)));
+    PH_CHECK(pool_malloc((void **)&s->ws.radiance, rays * sizeof(double)));
     s->ws_rays = rays;
     s->ws.stride = (unsigned)rays;
     return 0;
@@ -1755,12 +1837,12 @@ static int ensure_resume_state(photon_scene *s, bool linear, hipStream_t stream)
     const size_t rays = s->ws_rays, groups = (rays + 63) / 64;
     if (!s->ws.ctr) {
         unsigned *u = nullptr;
-        PH_CHECK(hipMalloc((void **)&u, (2 * rays + groups) * sizeof(unsigned)));
+        PH_CHECK(pool_malloc((void **)&u, (2 * rays + groups) * sizeof(unsigned)));
         s->ws.ctr = u; s->ws.spins = u + rays; s->ws.seg_flag = u + 2 * rays;
         PH_CHECK(hipMemsetAsync(s->ws.seg_flag, 0, groups * sizeof(unsigned), stream));
         s->march_epoch = 0;
     }
-    if (linear && !s->ws.vprev) PH_CHECK(hipMalloc((void **)&s->ws.vprev, 4 * rays * sizeof(float)));
+    if (linear && !s->ws.vprev) PH_CHECK(pool_malloc((void **)&s->ws.vprev, 4 * rays * sizeof(float)));
     if (++s->march_epoch >= (1u << 24)) {
         PH_CHECK(hipMemsetAsync(s->ws.seg_flag, 0, groups * sizeof(unsigned), stream));
         s->march_epoch = 1;
@@ -1801,9 +1883,9 @@ static int ensure_source_order(photon_scene *s, long long src_begin, long long s
         if (!slot || (!p.d_perm && slot->d_perm) || (!!p.d_perm == !!slot->d_perm && p.stamp < slot->stamp)) slot = &p;
     slot->begin = slot->end = -1;
     if (slot->capacity < n || !slot->d_perm) {
-        if (slot->d_perm) { (void)hipFree(slot->d_perm); slot->d_perm = nullptr; }
+        if (slot->d_perm) { pool_free(slot->d_perm); slot->d_perm = nullptr; }
         slot->capacity = 0;
-        PH_CHECK(hipMalloc((void **)&slot->d_perm, std::max<size_t>(n, 1) * sizeof(int)));
+        PH_CHECK(pool_malloc((void **)&slot->d_perm, std::max<size_t>(n, 1) * sizeof(int)));
         slot->capacity = n;
     }
     const int rc = photon_morton_order(s->dev.sx, s->dev.sy, (int)src_begin, (long long)n, slot->d_perm, stream, &s->sort_scratch);
@@ -2052,11 +2134,11 @@ extern "C" int photon_scene_set_march_profile(photon_scene_t *scene, int on) {
     if (!scene) return 1;
     return guarded("photon_scene_set_march_profile", [&]() -> int {
         if (on && !scene->d_profile) {
-            PH_CHECK(hipMalloc((void **)&scene->d_profile, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
+            PH_CHECK(pool_malloc((void **)&scene->d_profile, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
             PH_CHECK(hipMemset(scene->d_profile, 0, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
         } else if (!on && scene->d_profile) {
             PH_CHECK(hipDeviceSynchronize());
-            (void)hipFree(scene->d_profile);
+            pool_free(scene->d_profile);
             scene->d_profile = nullptr;
         }
         scene->prof_next = 0;
@@ -2650,13 +2732,17 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
     }
     photon_scene *scene = nullptr;
     float *d_image = nullptr, *d_fpos = nullptr, *d_fdir = nullptr, *d_ipos = nullptr, *d_idir = nullptr;
+    // PHOTON_VERBOSE: where a call's time goes beside the trace itself (scene upload, volume, image in / out, frees)
+    auto t_prev = t0;
+    double t_scene = 0, t_volume = 0, t_image_in = 0, t_trace = 0, t_image_out = 0;
+    auto lap = [&](double &acc) { const auto now = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
     auto cleanup = [&]() {
         if (scene) photon_scene_free(scene);
-        if (d_image) (void)hipFree(d_image);
-        if (d_fpos) (void)hipFree(d_fpos);
-        if (d_fdir) (void)hipFree(d_fdir);
-        if (d_ipos) (void)hipFree(d_ipos);
-        if (d_idir) (void)hipFree(d_idir);
+        pool_free(d_image);
+        pool_free(d_fpos);
+        pool_free(d_fdir);
+        pool_free(d_ipos);
+        pool_free(d_idir);
     };
 #define PH_VOID(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fprintf(stderr, "photon: HIP error %d (%s) at %s:%d; image left untouched\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); cleanup(); return; } } while (0)
     if (photon_scene_create(lens_pitch, image_distance, scattering_data_p, scattering_type_str, lightfield_source_p,
@@ -2666,6 +2752,7 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
         fprintf(stderr, "photon: scene upload failed; image left untouched\n");
         return;
     }
+    lap(t_scene);
     {   // noise hooks: same switches as the reference; seed from the environment instead of time(NULL)
         const char *e = getenv("PHOTON_NOISE_SEED");
         const uint64_t seed = e ? strtoull(e, nullptr, 0) : 0x5eedULL;
@@ -2681,10 +2768,12 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
         if (cached_volume(density_grad_filename, interpolation_from_env(), &vol)) { cleanup(); return; }
         photon_volume_set_weight_bits(vol, weight_bits_from_env());
     }
+    lap(t_volume);
     const int W = camera_design_p->x_pixel_number, H = camera_design_p->y_pixel_number;
     const size_t npix = (size_t)W * H;
-    PH_VOID(hipMalloc((void **)&d_image, npix * sizeof(float)));
+    PH_VOID(pool_malloc((void **)&d_image, npix * sizeof(float)));
     PH_VOID(hipMemcpy(d_image, image_array, npix * sizeof(float), hipMemcpyHostToDevice));     // .cu:3309
+    lap(t_image_in);
 
     const long long num_particles = lightfield_source_p->num_particles;
     const long long rps = lightray_number_per_particle;
@@ -2701,16 +2790,16 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
             return;
         }
         const size_t nsave = (size_t)num_lightrays_save * 3;
-        PH_VOID(hipMalloc((void **)&d_fpos, nsave * sizeof(float)));
-        PH_VOID(hipMalloc((void **)&d_fdir, nsave * sizeof(float)));
+        PH_VOID(pool_malloc((void **)&d_fpos, nsave * sizeof(float)));
+        PH_VOID(pool_malloc((void **)&d_fdir, nsave * sizeof(float)));
         std::vector<float> host(nsave);
         // intermediate dumps ride on the same chunking (.cu:3484-3492, 3535-3546, 3613-3670)
         const bool inter = simulate_density_gradients && save_intermediate_ray_data && num_intermediate_positions_save > 0;
         const size_t ninter = inter ? nsave * (size_t)num_intermediate_positions_save : 0;
         std::vector<float> host_inter(ninter);
         if (inter) {
-            PH_VOID(hipMalloc((void **)&d_ipos, ninter * sizeof(float)));
-            PH_VOID(hipMalloc((void **)&d_idir, ninter * sizeof(float)));
+            PH_VOID(pool_malloc((void **)&d_ipos, ninter * sizeof(float)));
+            PH_VOID(pool_malloc((void **)&d_idir, ninter * sizeof(float)));
         }
         const long long kmax = (num_particles + chunk - 1) / chunk;
         rc = begin_accumulate(scene, nullptr);
@@ -2751,18 +2840,24 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
         return;
     }
     PH_VOID(hipDeviceSynchronize());
+    lap(t_trace);
     if (march_error_check(scene)) {
         fprintf(stderr, "photon: trace failed; image left untouched\n");
         cleanup();
         return;
     }
     PH_VOID(hipMemcpy(image_array, d_image, npix * sizeof(float), hipMemcpyDeviceToHost));     // .cu:3675
+    lap(t_image_out);
 #undef PH_VOID
     cleanup();
     if (verbose()) {
+        double t_free = 0;
+        lap(t_free);
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("photon: %lld sources x %lld rays in %.3f s (%.2f Mrays/s incl. transfers)\n", num_particles, rps, s,
                num_particles * rps / s * 1e-6);
+        printf("photon:   scene upload %.2f ms, volume %.2f, image in %.2f, trace (launches + wait) %.2f, image out %.2f, frees %.2f\n",
+               t_scene, t_volume, t_image_in, t_trace, t_image_out, t_free);
     }
 }
 
