@@ -518,7 +518,7 @@ def main():
         scene.trace(side_image.data_ptr(), volume, args.algorithm, src_begin, src_end, stream=stream, want_stats=False)
 
     march_profile = None
-    if rank == 0 and windowed and lib.has_march_profile and not args.no_profile:
+    if rank == 0 and windowed and lib.has_march_profile and not args.no_profile and not os.environ.get("PHOTON_BENCH_CHILD"):
         scene.set_march_profile(True)
         scene.stats_begin(stream)
         for _ in range(min(args.steps, 10)):

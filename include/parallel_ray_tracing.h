@@ -282,7 +282,8 @@ unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub);
  * for ~2 ms and a launch ends when its last group does, so the chip idles for most of a group time at the end of every
  * launch; a launch of several chip fills therefore cuts every march into `segments` pieces of equal trip count, handed out
  * breadth-first, and a ray's loop state travels with it from piece to piece.  -1 (default) = the library's choice
- * (PHOTON_MARCH_SEGMENTS, 8, in launches of at least 1.25 chip fills), 1 = whole marches, 2..64 = that many in every
+ * (at most PHOTON_MARCH_SEGMENTS, 32, in launches of at least 1.25 chip fills: more pieces the shorter the launch and the
+ * longer a march), 1 = whole marches, 2..64 = that many in every
  * launch, whatever its size (tests).  Launches that write intermediate ray dumps or use gradient noise are never segmented.
  * start_ray_tracing reads PHOTON_MARCH_SEGMENTS=<n> (the library's choice) or force:<n> (every launch). */
 int photon_scene_set_march_segments(photon_scene_t *scene, int segments);
@@ -356,6 +357,13 @@ int photon_scene_march_profile(photon_scene_t *scene, photon_march_profile_t *ou
  * steps (optional) receives the per-ray completed iteration count. */
 int photon_trace_volume_rays(const photon_volume_t *vol, int ray_tracing_algorithm, int n,
                              float *pos, float *dir, int *steps);
+
+/* The same march for arbitrary rays, but THROUGH the render path's march launch -- persistent waves over the work queues,
+ * marches cut into `segments` pieces (-1 the library's choice, 1 whole, 2..64 forced): what the adversarial parity tests
+ * drive (rays from every side, tiny grids, the below-minimum repair) to hold the segmented march to the oracle's bits.
+ * ray_tracing_algorithm 1 or 2.  Results in place. */
+int photon_trace_volume_rays_queued(const photon_volume_t *vol, int ray_tracing_algorithm, int n, float *pos, float *dir,
+                                    int segments);
 
 /* ------------------------------------------------------------------------------------
  * Section 3: scene generation on the device (the step right before the

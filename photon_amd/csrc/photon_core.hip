@@ -530,7 +530,7 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 #define PHOTON_MARCH_PERSISTENT 1
 #endif
 #ifndef PHOTON_MARCH_SEGMENTS
-#define PHOTON_MARCH_SEGMENTS 8         // segments a ray's march is cut into in launches of several chip fills (march_group)
+#define PHOTON_MARCH_SEGMENTS 32        // most segments a ray's march is cut into in launches of several chip fills (launch_march picks)
 #endif
 constexpr unsigned kQueueStride = 16;                           // u32 per queue counter: one 64-byte line each
 #ifndef PHOTON_SUBQUEUES
@@ -1082,6 +1082,7 @@ struct photon_scene {
 };
 
 static void free_resume_state(photon_scene *s);
+static int march_error_check(photon_scene *scene);
 
 template <typename T>
 static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
@@ -1962,6 +1963,70 @@ static int march_segments_default(bool *forced) {
     return v > 64 ? 64 : v;
 }
 
+// The march launch of n rays whose state sits in the scene's workspace (stage 1b): persistent grid, work queues, segments.
+static int launch_march(photon_scene *s, const photon_volume *vol, int algorithm, unsigned n, unsigned long long ray_base,
+                        const InterDump &idump, bool save, hipStream_t stream, hipEvent_t ev_march_begin) {
+    const dim3 block(256), grid((n + 255) / 256);
+    const int interp = vol->dev.interpolation;
+    const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
+    // persistent waves: a grid that fills the chip once (more workgroups than fit only find empty queues and leave)
+    const unsigned all_blocks = (n + PHOTON_MARCH_BLOCK - 1) / PHOTON_MARCH_BLOCK;
+    const unsigned fill_blocks = (unsigned)s->num_cus * 8u * (256 / PHOTON_MARCH_BLOCK);
+    const dim3 mblock(PHOTON_MARCH_BLOCK), mgrid(PHOTON_MARCH_PERSISTENT ? std::min(all_blocks, fill_blocks) : all_blocks);
+    if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2))
+        PH_CHECK(hipMemsetAsync(s->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned), stream));
+    if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
+    unsigned long long *profile = nullptr;                  // wave timing of this launch, while there are free slots
+    if (s->d_profile && s->prof_next < kProfileLaunches && (algorithm == 1 || algorithm == 2))
+        profile = s->d_profile + (size_t)(s->prof_next++) * kProfileSub * PF_N;
+    // Segments: only where the launch is several times what the chip holds at once (a segment's wave then finds the
+    // previous segment of its group long done) and nothing indexes a ray's iterations (dumps, gradient noise).
+    unsigned segments = 1, seg_trips = 0;
+    if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2) && !save && !s->dev.noise.add_ngrad) {
+        const unsigned groups = (n + 63u) / 64u;
+        // resident march waves: five per SIMD (the launch bound of the march kernels)
+        const unsigned slots = (unsigned)s->num_cus * 4u * PHOTON_MARCH_WAVES;
+        bool forced = s->march_segments > 1;                // an explicit count segments launches of any size (tests)
+        const int want = s->march_segments >= 0 ? s->march_segments : march_segments_default(&forced);
+        if (want > 1 && (forced || groups >= slots + slots / 4)) {
+            // How many.  A launch of R chip fills of groups that march for L each costs R (L + S c) + 0.75 L / S: every
+            // hand-off costs c (flag poll, state round trip, tile refetch), the drain is 0.75 of a piece.  Minimum at
+            // S = sqrt(0.75 L / (R c)).  Measured on C3 (tools/segments_sweep.sh; tricubic / trilinear RK4, full job R = 30.5
+            // and one GPU's eighth R = 3.8): optima 4 / 2-3 and 12-16 / 6-8 -- the model's 4.0 / 2.3 and 11.3 / 6.5 with
+            // c = 2.9 us and L = 0.82 us per unit of work, a unit being one trilinear sample per texel of depth (x3 for RK4's
+            // three samples, x3 for the 64-tap sampler: RK4 tricubic through 256 texels = 2304 units = 1.9 ms).
+            const unsigned depth = (unsigned)std::max(vol->dev.nx, std::max(vol->dev.ny, vol->dev.nz));
+            segments = (unsigned)std::min(want, 64);
+            if (!forced) {
+                const double units = (double)depth * (algorithm == 2 ? 3.0 : 1.0) * (interp == 2 ? 3.0 : 1.0);
+                const double fills = (double)groups / (double)slots;
+                const unsigned best = (unsigned)(sqrt(0.212 * units / fills) + 0.5);
+                segments = std::max(1u, std::min(std::min(segments, best), depth / 4u));
+            }
+            seg_trips = std::max(4u, (depth + segments - 1) / segments);
+            if (segments > 1) { const int rc = ensure_resume_state(s, interp == 1, stream); if (rc) return rc; }
+        }
+    }
+    const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue, profile,
+                          segments, seg_trips, s->march_epoch, s->d_error};
+#define PH_MARCH(A, I, S, N) do { if (!S && !N && segments > 1) hipLaunchKernelGGL((march_kernel<A, I, false, false, true>), mgrid, mblock, 0, stream, margs); \
+                              else hipLaunchKernelGGL((march_kernel<A, I, S, N, false>), mgrid, mblock, 0, stream, margs); } while (0)
+    if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
+    else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
+    else if (algorithm != 1 && algorithm != 2) hipLaunchKernelGGL((march_extra_kernel<0>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
+    else if (algorithm == 1 && interp == 1) {              // the gradient-noise hook exists in this branch only (.h:853-863)
+        const bool ngrad = s->dev.noise.add_ngrad != 0;
+        if (save) { if (ngrad) PH_MARCH(1, 1, true, true); else PH_MARCH(1, 1, true, false); }
+        else { if (ngrad) PH_MARCH(1, 1, false, true); else PH_MARCH(1, 1, false, false); }
+    }
+    else if (algorithm == 1) PH_MARCH(1, 2, false, false);
+    else if (interp == 1) { if (save) PH_MARCH(2, 1, true, false); else PH_MARCH(2, 1, false, false); }
+    else PH_MARCH(2, 2, false, false);
+#undef PH_MARCH
+    PH_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
                         long long src_end, DumpDev dump, hipStream_t stream, hipEvent_t ev_march_begin, hipEvent_t ev_march_end) {
     double *d_image = s->d_acc;
@@ -1990,62 +2055,11 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
         hipLaunchKernelGGL(raygen_kernel, grid, block, 0, stream, s->dev, src_begin, n, s->ws);
         PH_CHECK(hipGetLastError());
         const int interp = vol->dev.interpolation;
-        const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
         const unsigned long long ray_base = (unsigned long long)(s->dev.source_base + src_begin) * (unsigned)s->dev.rays_per_source;
         const InterDump idump{dump.inter_pos, dump.inter_dir, dump.inter_slots, dump.num_save, 0u};
         const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
-        // persistent waves: a grid that fills the chip once (more workgroups than fit only find empty queues and leave)
-        const unsigned all_blocks = (n + PHOTON_MARCH_BLOCK - 1) / PHOTON_MARCH_BLOCK;
-        const unsigned fill_blocks = (unsigned)s->num_cus * 8u * (256 / PHOTON_MARCH_BLOCK);
-        const dim3 mblock(PHOTON_MARCH_BLOCK), mgrid(PHOTON_MARCH_PERSISTENT ? std::min(all_blocks, fill_blocks) : all_blocks);
-        if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2))
-            PH_CHECK(hipMemsetAsync(s->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned), stream));
-        if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
-        unsigned long long *profile = nullptr;                  // wave timing of this launch, while there are free slots
-        if (s->d_profile && s->prof_next < kProfileLaunches && (algorithm == 1 || algorithm == 2))
-            profile = s->d_profile + (size_t)(s->prof_next++) * kProfileSub * PF_N;
-        // Segments: only where the launch is several times what the chip holds at once (a segment's wave then finds the
-        // previous segment of its group long done) and nothing indexes a ray's iterations (dumps, gradient noise).
-        unsigned segments = 1, seg_trips = 0;
-        if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2) && !save && !s->dev.noise.add_ngrad) {
-            const unsigned groups = (n + 63u) / 64u;
-            // resident march waves: five per SIMD (the launch bound of the march kernels)
-            const unsigned slots = (unsigned)s->num_cus * 4u * PHOTON_MARCH_WAVES;
-            bool forced = s->march_segments > 1;                // an explicit count segments launches of any size (tests)
-            const int want = s->march_segments >= 0 ? s->march_segments : march_segments_default(&forced);
-            if (want > 1 && (forced || groups >= slots + slots / 4)) {
-                // How many: a segment should last ~0.25 ms -- the hand-off costs a few microseconds (flag poll, state round trip,
-                // tile refetch), and measured on C3 with 8 segments whatever the kernel: RK4 tricubic (1.9 ms per group) 59.06 ->
-                // 58.26 ms, RK4 trilinear (0.63 ms) 19.9 -> 20.8, Euler trilinear (0.24 ms) 7.5 -> 10.1.  Work of a group in
-                // units of one trilinear sample per texel of depth: x3 for RK4's three samples, x3 for the 64-tap sampler;
-                // 288 units per segment is RK4 tricubic through 256 texels in 8 pieces.
-                const unsigned depth = (unsigned)std::max(vol->dev.nx, std::max(vol->dev.ny, vol->dev.nz));
-                segments = (unsigned)std::min(want, 64);
-                if (!forced) {
-                    const unsigned units = depth * (algorithm == 2 ? 3u : 1u) * (interp == 2 ? 3u : 1u);
-                    segments = std::max(1u, std::min(segments, (units + 144u) / 288u));
-                }
-                seg_trips = std::max(4u, (depth + segments - 1) / segments);
-                if (segments > 1) { rc = ensure_resume_state(s, interp == 1, stream); if (rc) return rc; }
-            }
-        }
-        const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue, profile,
-                              segments, seg_trips, s->march_epoch, s->d_error};
-#define PH_MARCH(A, I, S, N) do { if (!S && !N && segments > 1) hipLaunchKernelGGL((march_kernel<A, I, false, false, true>), mgrid, mblock, 0, stream, margs); \
-                                  else hipLaunchKernelGGL((march_kernel<A, I, S, N, false>), mgrid, mblock, 0, stream, margs); } while (0)
-        if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
-        else if (algorithm == 4) hipLaunchKernelGGL((march_extra_kernel<4>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
-        else if (algorithm != 1 && algorithm != 2) hipLaunchKernelGGL((march_extra_kernel<0>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
-        else if (algorithm == 1 && interp == 1) {              // the gradient-noise hook exists in this branch only (.h:853-863)
-            const bool ngrad = s->dev.noise.add_ngrad != 0;
-            if (save) { if (ngrad) PH_MARCH(1, 1, true, true); else PH_MARCH(1, 1, true, false); }
-            else { if (ngrad) PH_MARCH(1, 1, false, true); else PH_MARCH(1, 1, false, false); }
-        }
-        else if (algorithm == 1) PH_MARCH(1, 2, false, false);
-        else if (interp == 1) { if (save) PH_MARCH(2, 1, true, false); else PH_MARCH(2, 1, false, false); }
-        else PH_MARCH(2, 2, false, false);
-#undef PH_MARCH
-        PH_CHECK(hipGetLastError());
+        rc = launch_march(s, vol, algorithm, n, ray_base, idump, save, stream, ev_march_begin);
+        if (rc) return rc;
         if (ev_march_end) PH_CHECK(hipEventRecord(ev_march_end, stream));
         // erf splats: optics and splat as two kernels (each gets the register file to itself); the 4-pixel
         // splat is done in place by the first
@@ -2065,6 +2079,44 @@ static int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm
     }
     PH_CHECK(hipGetLastError());
     return 0;
+}
+
+// March-only entry point THROUGH the render path's march launch (persistent waves, work queues, segments) for arbitrary
+// rays: what the adversarial parity tests drive (photon_trace_volume_rays runs a plain one-thread-per-ray grid instead).
+extern "C" int photon_trace_volume_rays_queued(const photon_volume_t *vol, int ray_tracing_algorithm, int n, float *pos, float *dir,
+                                               int segments) {
+    if (!vol || !pos || !dir || n < 0 || (unsigned)n > kMaxRaysPerLaunch || segments == 0 || segments < -1 || segments > 64 ||
+        (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2)) return 1;
+    if (n == 0) return 0;
+    return guarded("photon_trace_volume_rays_queued", [&]() -> int {
+        photon_scene sc;                                        // a bare scene: only what the march launch touches
+        struct Cleanup { photon_scene *s; ~Cleanup() {
+            pool_free(s->ws.px); pool_free(s->ws.radiance); free_resume_state(s);
+            pool_free(s->d_counters); pool_free(s->d_queue); pool_free(s->d_error);
+        } } cleanup{&sc};
+        sc.march_segments = segments;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) sc.num_cus = cus;
+        PH_CHECK(pool_malloc((void **)&sc.d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
+        PH_CHECK(hipMemset(sc.d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
+        PH_CHECK(pool_malloc((void **)&sc.d_queue, kQueues * kQueueStride * sizeof(unsigned)));
+        PH_CHECK(pool_malloc((void **)&sc.d_error, sizeof(unsigned)));
+        PH_CHECK(hipMemset(sc.d_error, 0, sizeof(unsigned)));
+        { const int rc = ensure_workspace(&sc, (size_t)n); if (rc) return rc; }
+        std::vector<float> soa((size_t)n * 6);
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++) { soa[(size_t)c * n + i] = pos[3 * i + c]; soa[(size_t)(3 + c) * n + i] = dir[3 * i + c]; }
+        float *arrays[6] = {sc.ws.px, sc.ws.py, sc.ws.pz, sc.ws.dx, sc.ws.dy, sc.ws.dz};
+        for (int c = 0; c < 6; c++) PH_CHECK(hipMemcpy(arrays[c], soa.data() + (size_t)c * n, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        const InterDump no_dump{nullptr, nullptr, 0, 0, 0u};
+        { const int rc = launch_march(&sc, vol, ray_tracing_algorithm, (unsigned)n, 0ull, no_dump, false, nullptr, nullptr); if (rc) return rc; }
+        PH_CHECK(hipDeviceSynchronize());
+        { const int rc = march_error_check(&sc); if (rc) return rc; }
+        for (int c = 0; c < 6; c++) PH_CHECK(hipMemcpy(soa.data() + (size_t)c * n, arrays[c], (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++) { pos[3 * i + c] = soa[(size_t)c * n + i]; dir[3 * i + c] = soa[(size_t)(3 + c) * n + i]; }
+        return 0;
+    });
 }
 
 constexpr unsigned kWindowMaxTraces = 1u << 16;        // traces per statistics window (each keeps a few HIP events alive)

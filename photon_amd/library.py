@@ -23,7 +23,7 @@ DECLARED_SYMBOLS = (
     "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_size",
     "photon_scene_set_march_segments", "photon_trim_caches", "photon_trace",
     "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_set_march_profile", "photon_scene_march_profile",
-    "photon_trace_volume_rays", "photon_version",
+    "photon_trace_volume_rays", "photon_trace_volume_rays_queued", "photon_version",
     # section 3: scene generation on the device
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
     "photon_scene_create_from_sources", "photon_volume_gaussian", "photon_density_gaussian_write_nrrd",
@@ -370,6 +370,15 @@ class Volume:
         self._lib._check(self._lib.lib.photon_trace_volume_rays(self.handle, int(algorithm), p.shape[0], _ptr(p),
                                                                 _ptr(d), _ptr(steps)), "photon_trace_volume_rays")
         return p, d, steps
+
+    def trace_rays_queued(self, pos: np.ndarray, direction: np.ndarray, algorithm: int = 2, segments: int = -1):
+        """The march of trace_rays through the render path's launch (persistent waves, work queues, `segments` pieces)."""
+        p = np.array(pos, dtype=np.float32, order="C").reshape(-1, 3)
+        d = np.array(direction, dtype=np.float32, order="C").reshape(-1, 3)
+        f = self._lib.lib.photon_trace_volume_rays_queued
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        self._lib._check(f(self.handle, int(algorithm), p.shape[0], _ptr(p), _ptr(d), int(segments)), "photon_trace_volume_rays_queued")
+        return p, d
 
     def free(self):
         if self.handle:

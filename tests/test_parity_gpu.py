@@ -205,6 +205,13 @@ def test_march_bit_exact_on_adversarial_cases(photon, oracle, seed):
                 assert np.array_equal(gs, os_), f"{what}: iteration counts differ at {np.flatnonzero(gs != os_)[:5]}"
                 assert_bit_equal(gp, op, what + " positions")
                 assert_bit_equal(gd, od, what + " directions")
+                # the same rays through the RENDER path's march launch -- persistent waves over the work queues -- whole and
+                # cut into 3 and 7 pieces, each piece waiting for the wave that marches the one before (64 groups on a chip
+                # of 5120 waves): the resume state (iterations, spins, the repair's last sampled value) must carry the bits
+                for segments in (1, 3, 7):
+                    qp, qd = g.trace_rays_queued(pos, d, algorithm, segments)
+                    assert_bit_equal(qp, op, what + f" positions, queued march in {segments} piece(s)")
+                    assert_bit_equal(qd, od, what + f" directions, queued march in {segments} piece(s)")
             if o2 is not o:
                 o2.free()
         assert gs.max() > 2

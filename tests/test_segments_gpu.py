@@ -89,8 +89,8 @@ def test_segment_counters_and_uneven_load(photon, volume_file, interp):
 
 def test_large_launch_is_segmented_by_default(photon, workdir):
     """2e6 rays = 31250 groups, six chip fills, through 128^3 (tricubic RK4: ~1 ms per group): the library segments on its
-    own (4 pieces of ~0.25 ms); same counters, same image as whole marches, and the launch's drain -- the average time a
-    wave slot stands empty at its end -- shrinks."""
+    own (its cost model picks 6 pieces here); same counters, same image as whole marches, and the launch's drain -- the
+    average time a wave slot stands empty at its end -- shrinks."""
     import torch
     rho, sp, org = scenes.bos_volume(128)
     volume_file = scenes.write_nrrd(os.path.join(workdir, "seg128.nrrd"), rho, sp, org)
