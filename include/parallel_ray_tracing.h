@@ -287,6 +287,11 @@ unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub);
  * launch, whatever its size (tests).  Launches that write intermediate ray dumps or use gradient noise are never segmented.
  * start_ray_tracing reads PHOTON_MARCH_SEGMENTS=<n> (the library's choice) or force:<n> (every launch). */
 int photon_scene_set_march_segments(photon_scene_t *scene, int segments);
+/* The library's own choice for a launch of n_rays through a volume whose longest axis has `depth` texels, on a device of
+ * num_cus compute units: returns the number of pieces (1 = whole marches), *halving (may be NULL) = 1 when their lengths
+ * halve (1/2, 1/4, ... of the depth) rather than being equal.  Pure host arithmetic (a cost model fitted to a sweep on C3:
+ * DESIGN.md section 4.1); for tests and documentation. */
+int photon_march_segments_plan(unsigned n_rays, int depth, int ray_tracing_algorithm, int interpolation, int num_cus, int *halving);
 
 /* A scene that holds only a SLICE of a job's source list (one rank of a multi-GPU job uploads just its shard): the
  * index, in the job's list, of this scene's first source.  Only the noise hooks read it -- their generator is keyed by the

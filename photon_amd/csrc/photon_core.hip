@@ -561,7 +561,9 @@ struct MarchArgs {
     unsigned *queue;
     unsigned long long *profile;        // this launch's wave-timing slots (photon_scene_set_march_profile), or nullptr
     unsigned segments;                  // segments every ray's march is cut into (1: whole marches, the state arrays below unused)
-    unsigned seg_trips;                 // trips of the march loop per segment (the last segment runs until every ray has left)
+    unsigned seg_trips;                 // uniform pieces: trips of the march loop per segment; halving pieces (bit 31 set): the
+                                        // depth D in trips -- segment s covers trips [D - (D >> s), D - (D >> (s + 1))).  Either
+                                        // way the last segment runs until every ray has left
     unsigned epoch;                     // tag of this launch in RayStateDev::seg_flag
     unsigned *error;                    // waves that gave a segment up (zero unless the hand-off between segments is broken)
 };
@@ -691,8 +693,12 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
                 }
             }
         }
-        if (!fresh) { rs.fresh = false; rs.trips_base = seg * a->seg_trips; }
-        if (SEG && seg + 1u < a->segments) rs.max_trips = a->seg_trips;
+        if (SEG) {
+            const unsigned st = a->seg_trips, depth = st & 0x7fffffffu;
+            const bool halving = (st >> 31) != 0u;              // wave-uniform
+            if (!fresh) { rs.fresh = false; rs.trips_base = halving ? depth - (depth >> seg) : seg * depth; }
+            if (seg + 1u < a->segments) rs.max_trips = halving ? (depth >> seg) - (depth >> (seg + 1u)) : depth;
+        }
         tot.n_marched += fresh ? (unsigned)__popcll(ballot(marching)) : 0u;
     }
     const VolumeDev vol = load_arg(&a->vol);
@@ -1963,6 +1969,62 @@ static int march_segments_default(bool *forced) {
     return v > 64 ? 64 : v;
 }
 
+// Pieces of a segmented march: of equal length, or halving (1/2, 1/4, ... of the depth).  Halving needs a third of the
+// hand-offs for the same final piece, but every pass then runs twice as fast as the one that feeds it: in a launch of few
+// chip fills its front catches up with the pieces it depends on and waves stand polling (measured, one GPU's eighth of C3,
+// 3.8 fills: 8.07-8.15 ms halving against 7.53-7.62 uniform; the full job, 30.5 fills: 56.95 against 57.28).  The front
+// stays clear while r / 2 <= R - 2 for every round r <= R of a pass, i.e. R >= 4; halving from 12 fills on, to be safe.
+// PHOTON_MARCH_SEGMENT_SHAPE=uniform|halving overrides (A/B runs, tests).
+static bool segments_halving(double fills) {
+    const char *e = getenv("PHOTON_MARCH_SEGMENT_SHAPE");
+    if (e && !strcmp(e, "uniform")) return false;
+    if (e && !strcmp(e, "halving")) return true;
+    return fills >= 12.0;
+}
+
+// How many pieces, and how long each.  Every hand-off costs c (flag poll, state round trip, tile refetch); the launch's drain
+// is 0.75 of its LAST pieces.  Equal pieces: a launch of R chip fills of groups that march for L each costs R (S - 1) c +
+// 0.75 L / S -- measured on C3 (tools/segments_sweep.sh; tricubic / trilinear RK4, full job R = 30.5, one GPU's eighth
+// R = 3.8): optima S = 4 / 2-3 and 12-16 / 6-8, the model's 4.0 / 2.3 and 11.3 / 6.5 with c = 2.9 us and L = 0.82 us per unit
+// of work (one trilinear sample per texel of depth; x3 for RK4's three samples, x3 for the 64-tap sampler: RK4 tricubic
+// through 256 texels = 2304 units = 1.9 ms).  Only the last pass's pieces need to be short, so in launches of many fills the
+// pieces HALVE (1/2, 1/4, ... of the depth; the last two equal; segments_halving): R (S - 1) c + 0.75 L / 2^(S-1).  Returns
+// the count that minimises that cost, at most `cap`; `forced` takes the cap itself (tests); the shortest piece is 4 trips.
+static unsigned plan_segments(unsigned groups, unsigned slots, unsigned depth, int algorithm, int interp, unsigned cap, bool forced,
+                              bool *halving_out) {
+    const double fills = (double)groups / (double)std::max(slots, 1u);
+    const bool halving = segments_halving(fills);
+    unsigned segments = std::max(cap, 1u);
+    if (!forced) {
+        const double units = (double)depth * (algorithm == 2 ? 3.0 : 1.0) * (interp == 2 ? 3.0 : 1.0);
+        const double L = 0.82 * units, c = 2.9;
+        unsigned best = 1;
+        double best_cost = 0.75 * L;
+        for (unsigned S = 2; S <= segments; S++) {
+            const double last = halving ? L / (double)(1u << std::min(S - 1u, 30u)) : L / S;      // the pieces of the last pass
+            const double cost = fills * (S - 1) * c + 0.75 * last;
+            if (cost < best_cost) { best_cost = cost; best = S; }
+        }
+        segments = best;
+    }
+    if (halving) while (segments > 1 && (segments - 1 >= 32u || (depth >> (segments - 1)) < 4u)) segments--;
+    else segments = std::max(1u, std::min(segments, depth / 4u));
+    *halving_out = halving && segments > 1;
+    return segments;
+}
+
+// The library's choice for a launch of n_rays through a volume of `depth` texels on a device of num_cus compute units
+// (host restatement for tests and documentation; PHOTON_MARCH_SEGMENT_SHAPE is honoured, PHOTON_MARCH_SEGMENTS is not).
+extern "C" int photon_march_segments_plan(unsigned n_rays, int depth, int ray_tracing_algorithm, int interpolation, int num_cus, int *halving) {
+    if (depth < 1 || num_cus < 1 || (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2)) return 0;
+    const unsigned groups = (n_rays + 63u) / 64u, slots = (unsigned)num_cus * 4u * PHOTON_MARCH_WAVES;
+    bool h = false;
+    unsigned s = 1;
+    if (PHOTON_MARCH_PERSISTENT && groups >= slots + slots / 4) s = plan_segments(groups, slots, (unsigned)depth, ray_tracing_algorithm, interpolation, PHOTON_MARCH_SEGMENTS, false, &h);
+    if (halving) *halving = h ? 1 : 0;
+    return (int)s;
+}
+
 // The march launch of n rays whose state sits in the scene's workspace (stage 1b): persistent grid, work queues, segments.
 static int launch_march(photon_scene *s, const photon_volume *vol, int algorithm, unsigned n, unsigned long long ray_base,
                         const InterDump &idump, bool save, hipStream_t stream, hipEvent_t ev_march_begin) {
@@ -1989,21 +2051,10 @@ static int launch_march(photon_scene *s, const photon_volume *vol, int algorithm
         bool forced = s->march_segments > 1;                // an explicit count segments launches of any size (tests)
         const int want = s->march_segments >= 0 ? s->march_segments : march_segments_default(&forced);
         if (want > 1 && (forced || groups >= slots + slots / 4)) {
-            // How many.  A launch of R chip fills of groups that march for L each costs R (L + S c) + 0.75 L / S: every
-            // hand-off costs c (flag poll, state round trip, tile refetch), the drain is 0.75 of a piece.  Minimum at
-            // S = sqrt(0.75 L / (R c)).  Measured on C3 (tools/segments_sweep.sh; tricubic / trilinear RK4, full job R = 30.5
-            // and one GPU's eighth R = 3.8): optima 4 / 2-3 and 12-16 / 6-8 -- the model's 4.0 / 2.3 and 11.3 / 6.5 with
-            // c = 2.9 us and L = 0.82 us per unit of work, a unit being one trilinear sample per texel of depth (x3 for RK4's
-            // three samples, x3 for the 64-tap sampler: RK4 tricubic through 256 texels = 2304 units = 1.9 ms).
             const unsigned depth = (unsigned)std::max(vol->dev.nx, std::max(vol->dev.ny, vol->dev.nz));
-            segments = (unsigned)std::min(want, 64);
-            if (!forced) {
-                const double units = (double)depth * (algorithm == 2 ? 3.0 : 1.0) * (interp == 2 ? 3.0 : 1.0);
-                const double fills = (double)groups / (double)slots;
-                const unsigned best = (unsigned)(sqrt(0.212 * units / fills) + 0.5);
-                segments = std::max(1u, std::min(std::min(segments, best), depth / 4u));
-            }
-            seg_trips = std::max(4u, (depth + segments - 1) / segments);
+            bool halving = false;
+            segments = plan_segments(groups, slots, depth, algorithm, interp, (unsigned)std::min(want, 64), forced, &halving);
+            seg_trips = halving ? (depth | 0x80000000u) : std::max(4u, (depth + segments - 1) / segments);
             if (segments > 1) { const int rc = ensure_resume_state(s, interp == 1, stream); if (rc) return rc; }
         }
     }

@@ -132,3 +132,33 @@ def test_march_work_queues_partition_every_launch():
                     k += 1
                 assert k == size(n_groups, x, sub), (n_groups, x, sub)
         assert (seen == 1).all(), n_groups
+
+
+def test_march_segments_plan():
+    """How many pieces the library cuts a ray's march into (photon_march_segments_plan: pure host arithmetic, the cost model
+    of DESIGN.md section 4.1 fitted to tools/segments_sweep.sh).  Pins the plan of the configurations that were measured: the
+    measured optima were 4 (equal) / 4-5 (halving) pieces for the C3 job with the tricubic sampler, 2-3 with the trilinear
+    one, 12-16 and 6-8 for one GPU's eighth of it; fast kernels and small launches march whole."""
+    import ctypes
+    from photon_amd import build
+    lib = ctypes.CDLL(build.build_library(verbose=False))
+    plan = lib.photon_march_segments_plan
+    plan.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    plan.restype = ctypes.c_int
+
+    def p(rays, depth, algo, interp, cus=256):
+        h = ctypes.c_int(-1)
+        return plan(rays, depth, algo, interp, cus, ctypes.byref(h)), h.value
+
+    os.environ.pop("PHOTON_MARCH_SEGMENT_SHAPE", None)
+    assert p(10_000_000, 256, 2, 2) in ((4, 1), (5, 1))          # C3 headline: 30.5 chip fills -> halving pieces
+    assert p(10_000_000, 256, 2, 1) in ((2, 1), (3, 1))          # the same with the trilinear sampler
+    s, h = p(1_250_000, 256, 2, 2)                               # one GPU's eighth: 3.8 fills -> equal pieces, many
+    assert h == 0 and 10 <= s <= 16
+    s, h = p(1_250_000, 256, 2, 1)
+    assert h == 0 and 5 <= s <= 8
+    assert p(10_000_000, 256, 1, 1) == (1, 0)                    # Euler trilinear: a march of 0.2 ms is not worth a hand-off
+    assert p(300_000, 256, 2, 2) == (1, 0)                       # less than 1.25 chip fills: whole marches
+    assert p(100_000_000 // 2, 512, 2, 2)[0] >= 2                # one launch of C4
+    assert p(10_000_000, 8, 2, 2)[0] <= 2                        # the shortest piece is 4 trips
+    assert plan(10_000_000, 256, 3, 2, 256, None) == 0           # integrators 3 / 4 are not segmented: refused

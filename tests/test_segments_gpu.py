@@ -26,8 +26,8 @@ def _dumps(photon, call, folder, segments, monkeypatch):
     """start_ray_tracing with the final ray dumps on: per-ray sensor hit and post-march direction, image."""
     monkeypatch.setenv("PHOTON_MARCH_SEGMENTS", segments)
     pdir, ddir = folder / f"pos_{segments.replace(':', '_')}", folder / f"dir_{segments.replace(':', '_')}"
-    pdir.mkdir()
-    ddir.mkdir()
+    pdir.mkdir(parents=True)
+    ddir.mkdir(parents=True)
     call.lightray_position_save_path, call.lightray_direction_save_path = str(pdir), str(ddir)
     img = photon.render(call)
     return (np.fromfile(pdir / "pos_0000.bin", np.float32), np.fromfile(ddir / "dir_0000.bin", np.float32), img)
@@ -45,11 +45,14 @@ def test_segmented_march_returns_the_bits_of_the_whole_march(photon, oracle, vol
     call.save_lightrays, call.num_lightrays_save = True, call.num_rays
     whole = _dumps(photon, call, tmp_path, "1", monkeypatch)
     assert np.isfinite(whole[0]).any()
-    for seg in ("force:2", "force:5", "force:64"):
-        got = _dumps(photon, call, tmp_path, seg, monkeypatch)
-        assert_bit_equal(got[0], whole[0], f"sensor hits, {seg}")
-        assert_bit_equal(got[1], whole[1], f"directions after the march, {seg}")
-        assert rel_l2(got[2], whole[2]) <= 1e-12            # same increments, f64 sums in another order
+    for shape in ("halving", "uniform"):                        # pieces of 1/2, 1/4, ... of the depth (shipped) / of equal length
+        monkeypatch.setenv("PHOTON_MARCH_SEGMENT_SHAPE", shape)
+        for seg in ("force:2", "force:5", "force:64"):
+            got = _dumps(photon, call, tmp_path / shape, seg, monkeypatch)
+            assert_bit_equal(got[0], whole[0], f"sensor hits, {seg} {shape}")
+            assert_bit_equal(got[1], whole[1], f"directions after the march, {seg} {shape}")
+            assert rel_l2(got[2], whole[2]) <= 1e-12        # same increments, f64 sums in another order
+    monkeypatch.delenv("PHOTON_MARCH_SEGMENT_SHAPE")
     cdir = tmp_path / "cpu"
     cdir.mkdir()
     call.lightray_position_save_path = call.lightray_direction_save_path = str(cdir)
