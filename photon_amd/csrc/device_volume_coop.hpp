@@ -30,6 +30,17 @@
 
 namespace photon {
 
+// Debug build only (-DPHOTON_PATH_STATS=1, tools/path_stats.py): how often a wave's sample takes which sampler path.
+#ifndef PHOTON_PATH_STATS
+#define PHOTON_PATH_STATS 0
+#endif
+#if PHOTON_PATH_STATS
+__device__ unsigned long long g_path_stats[8];      // 0 coherent samples, 1 tile fetches, 2 incoherent samples, 3 brick passes, 4 brick fetches, 5 gathered lanes, 6 lanes served per pass (sum)
+__device__ __forceinline__ void path_stat(int k, unsigned long long n = 1) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_path_stats[k], n); }
+#else
+__device__ __forceinline__ void path_stat(int, unsigned long long = 1) {}
+#endif
+
 #ifndef PHOTON_BRICK_PASSES
 #define PHOTON_BRICK_PASSES 6       // bricks parked per sample before the remaining lanes fall back to the per-lane gather
 #endif
@@ -368,7 +379,9 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         // the same (valid) tile and produces a value nobody uses.
         const Lead c = lead_of(need, fi, fj, fk);
         if ((same_block(c, fi, fj, fk) & need) == need) {       // wave-uniform
+            path_stat(0);
             if (!PHOTON_TILE_REUSE || c.i != parked.ti || c.j != parked.tj || c.k != parked.tk) {     // wave-uniform (SALU compares)
+                path_stat(1);
                 const int ci = (int)__int_as_float(c.i), cj = (int)__int_as_float(c.j), ck = (int)__int_as_float(c.k);
                 const int tx = clampi(ci - 1 + (lane & 3), 0, v.nx - 1), ty = clampi(cj - 1 + ((lane >> 2) & 3), 0, v.ny - 1),
                           tz = clampi(ck - 1 + (lane >> 4), 0, v.nz - 1);
@@ -393,6 +406,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     f4 acc = f4{0, 0, 0, 0};
     bool done = !lane_of(need);
     unsigned long long todo = need;
+    path_stat(2);
 #pragma unroll 1
     for (int pass = 0; pass < PHOTON_BRICK_PASSES && todo != 0; pass++) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -400,7 +414,10 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                   ck = __builtin_amdgcn_readlane(bk, leader);
         const int di = bi - ci + 2, dj = bj - cj + 2;
         const bool in_brick = !done && bk == ck && (unsigned)di <= 4u && (unsigned)dj <= 4u;
+        path_stat(3);
+        path_stat(6, (unsigned long long)__popcll(ballot(in_brick)));
         if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
+            path_stat(4);
             __builtin_amdgcn_wave_barrier();
             int l = lane;
             asm volatile("" : "+v"(l));                         // keep the brick's lane offsets out of the march loop's live registers
@@ -423,6 +440,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         __builtin_amdgcn_wave_barrier();
         todo = ballot(!done);
     }
+    path_stat(5, (unsigned long long)__popcll(ballot(!done)));
     if (!done) acc = cubic_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z);                       // stragglers
     return acc;
 }

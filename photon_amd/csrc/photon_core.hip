@@ -174,6 +174,17 @@ void pool_free(void *ptr) {
 
 extern "C" void photon_trim_caches(void) { pool_trim(0); }
 
+#if PHOTON_PATH_STATS
+// debug builds only: read (and clear) the sampler-path counters of device_volume_coop.hpp
+extern "C" int photon_debug_path_stats(unsigned long long out[8]) {
+    PH_CHECK(hipDeviceSynchronize());
+    PH_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(photon::g_path_stats), 8 * sizeof(unsigned long long)));
+    unsigned long long zero[8] = {};
+    PH_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(photon::g_path_stats), zero, sizeof zero));
+    return 0;
+}
+#endif
+
 // =============================================================================================
 // device-side aggregates
 // =============================================================================================
