@@ -429,7 +429,7 @@ def main():
 
     def make_call(seed=1, n_dots=args.dots, n_sources=None):
         c = scenes.bos_scene(n_dots=n_dots, points_per_dot=100, rays_per_source=args.rays_per_source,
-                             density_grad_filename=vol_path, seed=seed)
+                             density_grad_filename=vol_path, seed=seed, ray_tracing_algorithm=args.algorithm)
         if n_sources is not None:       # leading slice of the same source list
             for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
                 setattr(c, f, getattr(c, f)[:n_sources])
