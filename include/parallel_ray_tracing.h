@@ -268,15 +268,18 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
 int photon_scene_set_element_train(photon_scene_t *scene, int mode);
 
 /* The partition of a march launch over its work queues (host restatement of the kernel's own functions, for tests).
- * photon_march_queue_count() queues -- 8 XCDs x (count / 8) sub-queues, 32 in the shipped build; queue (xcd, sub) owns the
- * 8K-ray chunks c with c % count == sub * 8 + xcd.  photon_march_queue_group: index of the k-th 64-ray group that queue
- * hands out (grows with k); photon_march_queue_size: how many of a launch's n_groups groups it owns.  Every group of a
- * launch belongs to exactly one queue.  An xcd >= 8 or a sub >= count / 8 returns UINT_MAX.
+ * photon_march_queue_count() queues -- 8 XCDs x (count / 8) sub-queues, 32 in the shipped build; consecutive groups form
+ * CHUNKS of photon_march_queue_chunk(interpolation) groups (16 for the tricubic kernels, 128 for the trilinear ones), and
+ * queue (xcd, sub) owns the chunks c with c % count == sub * 8 + xcd.  photon_march_queue_group: index of the k-th 64-ray
+ * group that queue hands out (grows with k); photon_march_queue_size: how many of a launch's n_groups groups it owns.
+ * Every group of a launch belongs to exactly one queue.  An xcd >= 8, a sub >= count / 8 or a groups_per_chunk that is
+ * not a power of two up to 65536 returns UINT_MAX.
  * A launch whose marches are cut into S segments (photon_scene_set_march_segments) hands out size * S items per queue,
  * segment-major: item k is segment k / size of the queue's (k % size)-th group. */
 unsigned photon_march_queue_count(void);
-unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub);
-unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub);
+unsigned photon_march_queue_chunk(int interpolation);
+unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub, unsigned groups_per_chunk);
+unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub, unsigned groups_per_chunk);
 
 /* Segments per march (speed only; the image does not depend on it, nor do the marched rays: tests).  A 64-ray group marches
  * for ~2 ms and a launch ends when its last group does, so the chip idles for most of a group time at the end of every

@@ -534,7 +534,7 @@ __device__ __forceinline__ void clock_stamp(unsigned long long &clk, unsigned lo
 // generations lasted about G + 0.9 lifetimes -- one GPU's eighth of C3, 3.8 generations, ran at 81 % occupancy).
 // Here the grid is just large enough to fill the chip ONCE and every wave takes 64-ray groups from a queue until the
 // launch is served: a wave that finishes a group loads the next one itself, no slot waits for the dispatcher.
-// 32 queues, four per XCD (workgroup i runs on XCD i % 8), each handing out the groups of its 8K-ray chunks in order, so
+// 32 queues, four per XCD (workgroup i runs on XCD i % 8), each handing out the groups of its chunks (16 or 128 consecutive groups: kChunkShift*) in order, so
 // rays that walk the same voxels still meet in one L2 (what xcd_remap did for the one-shot launch); the visiting order and
 // why four are at the loop.  Every wave leaves as soon as its eleven queues are past their ends.
 #ifndef PHOTON_MARCH_PERSISTENT
@@ -549,11 +549,16 @@ constexpr unsigned kQueueStride = 16;                           // u32 per queue
 #endif
 constexpr unsigned kSubQueues = PHOTON_SUBQUEUES;
 constexpr unsigned kQueues = 64;                                // room for 8 XCDs x 8 sub-queues
-[[maybe_unused]] constexpr unsigned kGroupsPerChunk = PHOTON_XCD_CHUNK * 4;      // 64-ray groups per 8K-ray chunk
-// The k-th group handed out by sub-queue `sub` of XCD `xcd`: chunk ((k / C) * 8 + sub) * 8 + xcd, group k % C of it.  Grows
+// Consecutive 64-ray groups an XCD's queue owns as one CHUNK: 2^shift.  Large chunks keep the rays of neighbouring sources
+// in one L2; small ones balance the XCDs' queues at the end of a launch.  Measured on C3 with the segmented march (HBM
+// traffic does not care: 4.0-4.15 GB): tricubic RK4 march with chunks of 128 / 32 / 16 / 8 groups 57.70 / 57.59 / 57.53 /
+// 57.55 ms (one GPU's eighth 7.60 / 7.55 / 7.53 / 7.51), trilinear RK4 19.83 / 19.89 / 19.92: 16 for the tricubic kernels,
+// 128 for the trilinear ones (launch_march).
+constexpr unsigned kChunkShiftCubic = 4, kChunkShiftLinear = 7;
+// The k-th group handed out by sub-queue `sub` of XCD `xcd`, C = 2^shift groups per chunk: chunk ((k / C) * 4 + sub) * 8 + xcd, group k % C of it.  Grows
 // with k, so the first k whose group lies past the launch ends the queue; every group belongs to exactly one (xcd, sub).
-__host__ __device__ inline unsigned march_queue_group(unsigned k, unsigned xcd, unsigned sub) {
-    return (((k / kGroupsPerChunk) * kSubQueues + sub) * 8u + xcd) * kGroupsPerChunk + k % kGroupsPerChunk;
+__host__ __device__ inline unsigned march_queue_group(unsigned k, unsigned xcd, unsigned sub, unsigned shift) {
+    return ((((k >> shift) * kSubQueues + sub) * 8u + xcd) << shift) + (k & ((1u << shift) - 1u));
 }
 
 // The march kernel's arguments, read from the kernel-argument segment WHERE THEY ARE USED (scalar loads through a pointer
@@ -617,10 +622,10 @@ struct WaveTotals {
 };
 
 // Groups of a launch of n_groups that belong to queue (xcd, sub): its items are k = 0 .. that many - 1 (march_queue_group).
-__host__ __device__ inline unsigned march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub) {
+__host__ __device__ inline unsigned march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub, unsigned shift) {
     constexpr unsigned Q = 8u * kSubQueues;                     // chunk c belongs to queue c % Q = sub * 8 + xcd
-    const unsigned q = sub * 8u + xcd, full = n_groups / kGroupsPerChunk, rem = n_groups % kGroupsPerChunk;
-    return (full / Q + (full % Q > q ? 1u : 0u)) * kGroupsPerChunk + (full % Q == q ? rem : 0u);
+    const unsigned q = sub * 8u + xcd, full = n_groups >> shift, rem = n_groups & ((1u << shift) - 1u);
+    return ((full / Q + (full % Q > q ? 1u : 0u)) << shift) + (full % Q == q ? rem : 0u);
 }
 
 // Agent-scope relaxed accesses (global_load / global_store ... sc1): the loads bypass this CU's L1, the stores write
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, (march_waves<INTERP, NOISE>()))
         if (pf && lane == 0) atomicMax(&pf[PF_ENTER_NEGMIN], ~real_time());
     }
 #if PHOTON_MARCH_PERSISTENT
-    // 32 queues: XCD x (workgroup i runs on XCD i % 8) owns the 8K-ray chunks c with c % 8 == x, dealt over its four
+    // 32 queues: XCD x (workgroup i runs on XCD i % 8) owns the chunks c (16 or 128 consecutive groups) with c % 8 == x, dealt over its four
     // sub-queues by (c / 8) % 4; one counter per queue, a cache line apart.  A wave serves its home sub-queue, then the
     // other three of its XCD (between them the XCD's waves drain all four: every group is taken), then the same sub-queue
     // of the seven other XCDs (balance at the end of the launch).  How many sub-queues (same box, 1 / 2 / 4 / 8 per XCD):
@@ -790,11 +795,12 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, (march_waves<INTERP, NOISE>()))
             if (lane == 0) k = atomicAdd(&march_args()->queue[(sub * 8u + x) * kQueueStride], 1u);
             k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             const unsigned n_rays = march_args()->n_rays;
-            const unsigned gq = march_queue_size((n_rays + 63u) / 64u, x, sub);
+            const unsigned shift = INTERP == 2 ? kChunkShiftCubic : kChunkShiftLinear;
+            const unsigned gq = march_queue_size((n_rays + 63u) / 64u, x, sub, shift);
             const unsigned n_seg = SEG ? march_args()->segments : 1u;
             if (k >= gq * n_seg) break;                         // this queue is served (k < 2^26 / 64 * 255: no overflow)
             const unsigned seg = SEG ? k / gq : 0u;
-            march_group<ALGO, INTERP, SAVE, NOISE, SEG>(march_queue_group(k - seg * gq, x, sub), seg, n_rays, tile, tot);
+            march_group<ALGO, INTERP, SAVE, NOISE, SEG>(march_queue_group(k - seg * gq, x, sub, shift), seg, n_rays, tile, tot);
             if ((tot.mc.samples | tot.mc.iterations) >> 31) {     // wave-uniform: the 32-bit wave totals go out before they can wrap
                 if (lane == 0) {
                     unsigned long long *slot = counter_slot(march_args()->counters);
@@ -1790,11 +1796,18 @@ int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_n
 }
 
 unsigned photon_march_queue_count(void) { return 8u * kSubQueues; }
-unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub) {
-    return xcd < 8u && sub < kSubQueues ? march_queue_group(k, xcd, sub) : ~0u;
+unsigned photon_march_queue_chunk(int interpolation) { return 1u << (interpolation == 2 ? kChunkShiftCubic : kChunkShiftLinear); }
+static unsigned chunk_shift_of(unsigned groups_per_chunk) {    // log2 of a power of two in [1, 2^16]; 32 otherwise
+    for (unsigned s = 0; s <= 16; s++) if (groups_per_chunk == (1u << s)) return s;
+    return 32u;
 }
-unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub) {
-    return xcd < 8u && sub < kSubQueues ? march_queue_size(n_groups, xcd, sub) : ~0u;
+unsigned photon_march_queue_group(unsigned k, unsigned xcd, unsigned sub, unsigned groups_per_chunk) {
+    const unsigned shift = chunk_shift_of(groups_per_chunk);
+    return xcd < 8u && sub < kSubQueues && shift < 32u ? march_queue_group(k, xcd, sub, shift) : ~0u;
+}
+unsigned photon_march_queue_size(unsigned n_groups, unsigned xcd, unsigned sub, unsigned groups_per_chunk) {
+    const unsigned shift = chunk_shift_of(groups_per_chunk);
+    return xcd < 8u && sub < kSubQueues && shift < 32u ? march_queue_size(n_groups, xcd, sub, shift) : ~0u;
 }
 
 int photon_scene_set_source_base(photon_scene_t *s, int64_t first_source) {

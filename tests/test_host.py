@@ -98,40 +98,44 @@ def test_tiff_and_raw_writers_round_trip(tmp_path):
 def test_march_work_queues_partition_every_launch():
     """The work queues of the persistent march (8 XCDs x 4 sub-queues): for any number of 64-ray groups every group
     below it is handed out by exactly one queue, each queue hands its groups out in increasing order (so the first one
-    past the end ends the queue), and consecutive groups of an 8K-ray chunk come from ONE queue (L2 locality).  Host
-    restatement of the kernel's own function, through the C-ABI; no GPU needed."""
+    past the end ends the queue), and the consecutive groups of a chunk (16 groups for the tricubic kernels, 128 for the
+    trilinear ones) come from ONE queue (L2 locality).  Host restatement of the kernel's own functions, through the C-ABI; no
+    GPU needed."""
     import ctypes
     from photon_amd import build
     lib = ctypes.CDLL(build.build_library(verbose=False))
     f = lib.photon_march_queue_group
-    f.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    f.argtypes = [ctypes.c_uint] * 4
     f.restype = ctypes.c_uint
     size = lib.photon_march_queue_size
-    size.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    size.argtypes = [ctypes.c_uint] * 4
     size.restype = ctypes.c_uint
     lib.photon_march_queue_count.restype = ctypes.c_uint
+    lib.photon_march_queue_chunk.restype = ctypes.c_uint
     subs = lib.photon_march_queue_count() // 8
-    assert subs == 4
-    assert f(0, 8, 0) == 0xFFFFFFFF and f(0, 0, subs) == 0xFFFFFFFF and size(100, 0, subs) == 0xFFFFFFFF      # out of range: refused, not aliased
-    for n_groups in (1, 127, 128, 129, 1023, 8 * 128 + 5, 32 * 128 - 1, 32 * 128, 64 * 128, 64 * 128 + 1, 19532):
-        seen = np.zeros(n_groups, np.int32)
-        for x in range(8):
-            for sub in range(subs):
-                # a segmented launch hands out size x S items per queue, item k = segment k // size of group k % size:
-                # the closed form must count exactly the groups the queue's own enumeration finds below the launch's end
-                assert size(n_groups, x, sub) == sum(1 for k in range(n_groups) if f(k, x, sub) < n_groups) if n_groups < 2000 else True
-                last, k = -1, 0
-                while True:
-                    g = f(k, x, sub)
-                    assert g > last                    # monotonic: a queue ends at its first group past the launch
-                    last = g
-                    if g >= n_groups:
-                        break
-                    seen[g] += 1
-                    assert (g // 128) % 8 == x and (g // 128 // 8) % 4 == sub
-                    k += 1
-                assert k == size(n_groups, x, sub), (n_groups, x, sub)
-        assert (seen == 1).all(), n_groups
+    assert subs == 4 and lib.photon_march_queue_chunk(2) == 16 and lib.photon_march_queue_chunk(1) == 128
+    bad = 0xFFFFFFFF
+    assert f(0, 8, 0, 16) == bad and f(0, 0, subs, 16) == bad and size(100, 0, subs, 16) == bad     # out of range: refused, not aliased
+    assert f(0, 0, 0, 24) == bad and size(100, 0, 0, 0) == bad                                       # chunks are powers of two
+    for C in (16, 128):
+        for n_groups in (1, C - 1, C, C + 1, 1023, 8 * C + 5, 32 * C - 1, 32 * C, 64 * C, 64 * C + 1, 19532):
+            seen = np.zeros(n_groups, np.int32)
+            for x in range(8):
+                for sub in range(subs):
+                    last, k = -1, 0
+                    while True:
+                        g = f(k, x, sub, C)
+                        assert g > last                    # monotonic: a queue ends at its first group past the launch
+                        last = g
+                        if g >= n_groups:
+                            break
+                        seen[g] += 1
+                        assert (g // C) % 8 == x and (g // C // 8) % subs == sub
+                        k += 1
+                    # a segmented launch hands out size x S items per queue (item k = segment k // size of group k % size):
+                    # the closed form counts exactly the groups the queue's own enumeration finds below the launch's end
+                    assert k == size(n_groups, x, sub, C), (n_groups, x, sub, C)
+            assert (seen == 1).all(), (n_groups, C)
 
 
 def test_march_segments_plan():
