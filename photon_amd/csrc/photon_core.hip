@@ -565,6 +565,7 @@ __host__ __device__ inline unsigned march_queue_group(unsigned k, unsigned xcd, 
 // the optimiser cannot see through) instead of being held in SGPRs from the prologue on: the persistent loop needs them
 // again for every group, and ~55 argument SGPRs live across the march loop -- whose own constants, masks and tile ids take
 // ~60 -- overflowed the 102 a wave has (15-55 SGPRs spilled into VGPR lanes, and VGPRs into scratch).
+constexpr unsigned kMaxSegments = 64;
 struct MarchArgs {
     VolumeDev vol;
     const f4 *tex;
@@ -577,9 +578,8 @@ struct MarchArgs {
     unsigned *queue;
     unsigned long long *profile;        // this launch's wave-timing slots (photon_scene_set_march_profile), or nullptr
     unsigned segments;                  // segments every ray's march is cut into (1: whole marches, the state arrays below unused)
-    unsigned seg_trips;                 // uniform pieces: trips of the march loop per segment; halving pieces (bit 31 set): the
-                                        // depth D in trips -- segment s covers trips [D - (D >> s), D - (D >> (s + 1))).  Either
-                                        // way the last segment runs until every ray has left
+    unsigned seg_begin[kMaxSegments + 1];   // segment s covers the trips [seg_begin[s], seg_begin[s + 1]) of the march loop (the last
+                                        // one runs until every ray has left): equal, halving or tapered pieces (plan_segments)
     unsigned epoch;                     // tag of this launch in RayStateDev::seg_flag
     unsigned *error;                    // waves that gave a segment up (zero unless the hand-off between segments is broken)
 };
@@ -710,10 +710,9 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
             }
         }
         if (SEG) {
-            const unsigned st = a->seg_trips, depth = st & 0x7fffffffu;
-            const bool halving = (st >> 31) != 0u;              // wave-uniform
-            if (!fresh) { rs.fresh = false; rs.trips_base = halving ? depth - (depth >> seg) : seg * depth; }
-            if (seg + 1u < a->segments) rs.max_trips = halving ? (depth >> seg) - (depth >> (seg + 1u)) : depth;
+            const unsigned b0 = a->seg_begin[seg];              // wave-uniform index: scalar loads from the argument segment
+            if (!fresh) { rs.fresh = false; rs.trips_base = b0; }
+            if (seg + 1u < a->segments) rs.max_trips = a->seg_begin[seg + 1u] - b0;
         }
         tot.n_marched += fresh ? (unsigned)__popcll(ballot(marching)) : 0u;
     }
@@ -1993,48 +1992,79 @@ static int march_segments_default(bool *forced) {
     return v > 64 ? 64 : v;
 }
 
-// Pieces of a segmented march: of equal length, or halving (1/2, 1/4, ... of the depth).  Halving needs a third of the
-// hand-offs for the same final piece, but every pass then runs twice as fast as the one that feeds it: in a launch of few
-// chip fills its front catches up with the pieces it depends on and waves stand polling (measured, one GPU's eighth of C3,
-// 3.8 fills: 8.07-8.15 ms halving against 7.53-7.62 uniform; the full job, 30.5 fills: 56.95 against 57.28).  The front
-// stays clear while r / 2 <= R - 2 for every round r <= R of a pass, i.e. R >= 4; halving from 12 fills on, to be safe.
-// PHOTON_MARCH_SEGMENT_SHAPE=uniform|halving overrides (A/B runs, tests).
-static bool segments_halving(double fills) {
+// Shape of the pieces of a segmented march.  Equal pieces; HALVING pieces (1/2, 1/4, ... of the depth, the last two equal):
+// a third of the hand-offs for the same final piece, but every pass then runs twice as fast as the one that feeds it -- in a
+// launch of few chip fills its front catches up with the pieces it depends on and waves stand polling (measured, one GPU's
+// eighth of C3, 3.8 fills: 8.07-8.15 ms halving against 7.53-7.62 equal; the full job, 30.5 fills: 56.95 against 57.28; the
+// front stays clear while r / 2 <= R - 2 for every round r <= R of a pass: halving from 12 fills on); TAPERED pieces: equal
+// ones, the last of them halved t times (.., u, u/2, u/4, u/4 for t = 2) -- a short final pass without the long chain of
+// ever faster passes.  PHOTON_MARCH_SEGMENT_SHAPE=uniform|halving|taper:<t> overrides the choice (A/B runs, tests).
+enum SegShape { SEG_UNIFORM = 0, SEG_HALVING = 1, SEG_TAPER = 2 };
+static SegShape segment_shape(double fills, unsigned *taper) {
     const char *e = getenv("PHOTON_MARCH_SEGMENT_SHAPE");
-    if (e && !strcmp(e, "uniform")) return false;
-    if (e && !strcmp(e, "halving")) return true;
-    return fills >= 12.0;
+    *taper = 0;
+    if (e && !strcmp(e, "uniform")) return SEG_UNIFORM;
+    if (e && !strcmp(e, "halving")) return SEG_HALVING;
+    if (e && !strncmp(e, "taper:", 6)) { *taper = (unsigned)std::max(1, std::min(atoi(e + 6), 8)); return SEG_TAPER; }
+    return fills >= 12.0 ? SEG_HALVING : SEG_UNIFORM;
 }
 
-// How many pieces, and how long each.  Every hand-off costs c (flag poll, state round trip, tile refetch); the launch's drain
-// is 0.75 of its LAST pieces.  Equal pieces: a launch of R chip fills of groups that march for L each costs R (S - 1) c +
-// 0.75 L / S -- measured on C3 (tools/segments_sweep.sh; tricubic / trilinear RK4, full job R = 30.5, one GPU's eighth
-// R = 3.8): optima S = 4 / 2-3 and 12-16 / 6-8, the model's 4.0 / 2.3 and 11.3 / 6.5 with c = 2.9 us and L = 0.82 us per unit
-// of work (one trilinear sample per texel of depth; x3 for RK4's three samples, x3 for the 64-tap sampler: RK4 tricubic
-// through 256 texels = 2304 units = 1.9 ms).  Only the last pass's pieces need to be short, so in launches of many fills the
-// pieces HALVE (1/2, 1/4, ... of the depth; the last two equal; segments_halving): R (S - 1) c + 0.75 L / 2^(S-1).  Returns
-// the count that minimises that cost, at most `cap`; `forced` takes the cap itself (tests); the shortest piece is 4 trips.
+// How many pieces, and how long each: fills `begin` (begin[s] = first trip of piece s; begin[S] = depth) and returns S.
+// Every hand-off costs c (flag poll, state round trip, tile refetch); the launch's drain is 0.75 of its LAST pieces.  Equal
+// pieces: a launch of R chip fills of groups that march for L each costs R (S - 1) c + 0.75 L / S -- measured on C3
+// (tools/segments_sweep.sh; tricubic / trilinear RK4, full job R = 30.5, one GPU's eighth R = 3.8): optima S = 4 / 2-3 and
+// 12-16 / 6-8, the model's 4.0 / 2.3 and 11.3 / 6.5 with c = 2.9 us and L = 0.82 us per unit of work (one trilinear sample per
+// texel of depth; x3 for RK4's three samples, x3 for the 64-tap sampler: RK4 tricubic through 256 texels = 2304 units =
+// 1.9 ms).  Only the last pass's pieces need to be short: R (S - 1) c + 0.75 (last piece), minimised over S for the shape
+// in use.  At most `cap` pieces; `forced` takes the cap itself (tests); the shortest piece is 4 trips.
 static unsigned plan_segments(unsigned groups, unsigned slots, unsigned depth, int algorithm, int interp, unsigned cap, bool forced,
-                              bool *halving_out) {
+                              unsigned *begin, int *shape_out) {
     const double fills = (double)groups / (double)std::max(slots, 1u);
-    const bool halving = segments_halving(fills);
-    unsigned segments = std::max(cap, 1u);
+    unsigned taper = 0;
+    const SegShape shape = segment_shape(fills, &taper);
+    cap = std::max(1u, std::min(cap, kMaxSegments));
+    // lengths (as fractions of the depth) of the S pieces of a shape
+    auto lengths = [&](unsigned S) {
+        std::vector<double> len;
+        if (shape == SEG_HALVING) {
+            for (unsigned k = 1; k < S; k++) len.push_back(1.0 / (double)(1ull << std::min(k, 40u)));
+            len.push_back(S > 1 ? len.back() : 1.0);
+        } else {
+            const unsigned t = shape == SEG_TAPER ? std::min(taper, S - 1) : 0, base = S - t;
+            for (unsigned k = 0; k + 1 < base; k++) len.push_back(1.0 / base);
+            double u = 1.0 / base;
+            for (unsigned k = 0; k < t; k++) { u *= 0.5; len.push_back(u); }
+            len.push_back(u);
+        }
+        return len;
+    };
+    unsigned S = cap;
     if (!forced) {
         const double units = (double)depth * (algorithm == 2 ? 3.0 : 1.0) * (interp == 2 ? 3.0 : 1.0);
         const double L = 0.82 * units, c = 2.9;
-        unsigned best = 1;
         double best_cost = 0.75 * L;
-        for (unsigned S = 2; S <= segments; S++) {
-            const double last = halving ? L / (double)(1u << std::min(S - 1u, 30u)) : L / S;      // the pieces of the last pass
-            const double cost = fills * (S - 1) * c + 0.75 * last;
-            if (cost < best_cost) { best_cost = cost; best = S; }
+        S = 1;
+        for (unsigned k = 2; k <= cap; k++) {
+            const double cost = fills * (k - 1) * c + 0.75 * L * lengths(k).back();
+            if (cost < best_cost) { best_cost = cost; S = k; }
         }
-        segments = best;
     }
-    if (halving) while (segments > 1 && (segments - 1 >= 32u || (depth >> (segments - 1)) < 4u)) segments--;
-    else segments = std::max(1u, std::min(segments, depth / 4u));
-    *halving_out = halving && segments > 1;
-    return segments;
+    // boundaries in trips; pieces shorter than 4 trips are merged into their predecessor
+    for (;; S--) {
+        const std::vector<double> len = lengths(S);
+        double at = 0.0;
+        bool ok = true;
+        begin[0] = 0;
+        for (unsigned k = 0; k < S; k++) {
+            at += len[k];
+            begin[k + 1] = k + 1 == S ? depth : (unsigned)(at * depth + 0.5);
+            if (begin[k + 1] < begin[k] + 4u) ok = false;
+        }
+        if (ok || S == 1) break;
+    }
+    if (S == 1) { begin[0] = 0; begin[1] = depth; }
+    if (shape_out) *shape_out = S > 1 ? (int)shape : (int)SEG_UNIFORM;
+    return S;
 }
 
 // The library's choice for a launch of n_rays through a volume of `depth` texels on a device of num_cus compute units
@@ -2042,10 +2072,10 @@ static unsigned plan_segments(unsigned groups, unsigned slots, unsigned depth, i
 extern "C" int photon_march_segments_plan(unsigned n_rays, int depth, int ray_tracing_algorithm, int interpolation, int num_cus, int *halving) {
     if (depth < 1 || num_cus < 1 || (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2)) return 0;
     const unsigned groups = (n_rays + 63u) / 64u, slots = (unsigned)num_cus * 4u * PHOTON_MARCH_WAVES;
-    bool h = false;
-    unsigned s = 1;
-    if (PHOTON_MARCH_PERSISTENT && groups >= slots + slots / 4) s = plan_segments(groups, slots, (unsigned)depth, ray_tracing_algorithm, interpolation, PHOTON_MARCH_SEGMENTS, false, &h);
-    if (halving) *halving = h ? 1 : 0;
+    int shape = 0;
+    unsigned s = 1, begin[kMaxSegments + 1];
+    if (PHOTON_MARCH_PERSISTENT && groups >= slots + slots / 4) s = plan_segments(groups, slots, (unsigned)depth, ray_tracing_algorithm, interpolation, PHOTON_MARCH_SEGMENTS, false, begin, &shape);
+    if (halving) *halving = shape == SEG_HALVING ? 1 : 0;
     return (int)s;
 }
 
@@ -2067,7 +2097,8 @@ static int launch_march(photon_scene *s, const photon_volume *vol, int algorithm
         profile = s->d_profile + (size_t)(s->prof_next++) * kProfileSub * PF_N;
     // Segments: only where the launch is several times what the chip holds at once (a segment's wave then finds the
     // previous segment of its group long done) and nothing indexes a ray's iterations (dumps, gradient noise).
-    unsigned segments = 1, seg_trips = 0;
+    unsigned segments = 1;
+    MarchArgs margs{};
     if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2) && !save && !s->dev.noise.add_ngrad) {
         const unsigned groups = (n + 63u) / 64u;
         // resident march waves: five per SIMD (the launch bound of the march kernels)
@@ -2076,14 +2107,13 @@ static int launch_march(photon_scene *s, const photon_volume *vol, int algorithm
         const int want = s->march_segments >= 0 ? s->march_segments : march_segments_default(&forced);
         if (want > 1 && (forced || groups >= slots + slots / 4)) {
             const unsigned depth = (unsigned)std::max(vol->dev.nx, std::max(vol->dev.ny, vol->dev.nz));
-            bool halving = false;
-            segments = plan_segments(groups, slots, depth, algorithm, interp, (unsigned)std::min(want, 64), forced, &halving);
-            seg_trips = halving ? (depth | 0x80000000u) : std::max(4u, (depth + segments - 1) / segments);
+            segments = plan_segments(groups, slots, depth, algorithm, interp, (unsigned)std::min(want, 64), forced, margs.seg_begin, nullptr);
             if (segments > 1) { const int rc = ensure_resume_state(s, interp == 1, stream); if (rc) return rc; }
         }
     }
-    const MarchArgs margs{vol->dev, tex, n, s->ws, s->d_counters, s->dev.noise, ray_base, idump, s->d_queue, profile,
-                          segments, seg_trips, s->march_epoch, s->d_error};
+    margs.vol = vol->dev; margs.tex = tex; margs.n_rays = n; margs.st = s->ws; margs.counters = s->d_counters; margs.noise = s->dev.noise;
+    margs.ray_base = ray_base; margs.idump = idump; margs.queue = s->d_queue; margs.profile = profile; margs.segments = segments;
+    margs.epoch = s->march_epoch; margs.error = s->d_error;
 #define PH_MARCH(A, I, S, N) do { if (!S && !N && segments > 1) hipLaunchKernelGGL((march_kernel<A, I, false, false, true>), mgrid, mblock, 0, stream, margs); \
                               else hipLaunchKernelGGL((march_kernel<A, I, S, N, false>), mgrid, mblock, 0, stream, margs); } while (0)
     if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
