@@ -359,6 +359,10 @@ typedef struct photon_march_profile_t {
 } photon_march_profile_t;
 int photon_scene_set_march_profile(photon_scene_t *scene, int on);
 int photon_scene_march_profile(photon_scene_t *scene, photon_march_profile_t *out);
+/* The raw stamps of profiled launch `launch` (0 = the first since the reset): out[64][8] = per workgroup-index-mod-64 slot
+ * {~min entry, ~min first-group start, sum of starts, max start, ~min exit, sum of exits, max exit, waves} in ticks of the
+ * 100 MHz clock (slot & 7 = the XCD); for tools/tail_by_xcd.py. */
+int photon_scene_march_profile_raw(photon_scene_t *scene, unsigned launch, unsigned long long *out);
 
 /* March-only entry point for parity tests: n rays (host arrays pos/dir f32[n][3], world
  * frame) through trace_rays_through_density_gradients (.h:1455-1544); results in place,

@@ -2365,6 +2365,15 @@ static int march_error_check(photon_scene *scene) {
     return 1;
 }
 
+// The raw wave-timing slots of one profiled launch (64 sub-slots x 8 words: PF_*; sub-slot = workgroup index % 64, so
+// sub-slot & 7 is the XCD the workgroup ran on): for tools that look at the launch's end per XCD.
+extern "C" int photon_scene_march_profile_raw(photon_scene_t *scene, unsigned launch, unsigned long long *out) {
+    if (!scene || !out || !scene->d_profile || launch >= std::min(scene->prof_next, kProfileLaunches)) return 1;
+    PH_CHECK(hipDeviceSynchronize());
+    PH_CHECK(hipMemcpy(out, scene->d_profile + (size_t)launch * kProfileSub * PF_N, (size_t)kProfileSub * PF_N * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // Sum the counter slots into stats (the caller has made sure the device is done with them).
 static int read_counters(photon_scene *scene, bool have_volume, photon_trace_stats_t *stats) {
     std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);

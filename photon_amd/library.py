@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = (
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
     "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_chunk", "photon_march_queue_size",
     "photon_scene_set_march_segments", "photon_march_segments_plan", "photon_trim_caches", "photon_trace",
-    "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_set_march_profile", "photon_scene_march_profile",
+    "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_set_march_profile", "photon_scene_march_profile", "photon_scene_march_profile_raw",
     "photon_trace_volume_rays", "photon_trace_volume_rays_queued", "photon_version",
     # section 3: scene generation on the device
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
