@@ -192,7 +192,7 @@ struct RayStateDev {                // SoA ray state between the march and the s
     float *px, *py, *pz, *dx, *dy, *dz;
     double *radiance;
     // what a ray carries between the segments of a segmented march (device_volume_coop.hpp, MarchResume), per ray:
-    unsigned *ctr;                  // bit 31: still marching; bits 0-30: completed iterations
+    unsigned *ctr;                  // bit 31: still marching; bits 24-30: the segment that wrote the word; bits 0-23: completed iterations
     unsigned *spins;
     float *vprev;                   // [4][rays]: the last value sampled (trilinear branches)
     unsigned *seg_flag;             // per 64-ray group: (launch epoch << 8) | segments completed (0xff: every ray has left)
@@ -634,6 +634,10 @@ __host__ __device__ inline unsigned march_queue_size(unsigned n_groups, unsigned
 // own vmcnt(0), an sc1 flag; the reader polls the flag with an sc1 load, then loads the payload with sc1 loads only).
 template <class T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef PHOTON_SEG_ACQUIRE
+#define PHOTON_SEG_ACQUIRE 0            // 1: an agent-scope acquire (buffer_inv sc1) after the flag poll of every segment start
+#endif
+static_assert(kLoopMax < (1 << 24) - 1, "completed iterations travel in 24 bits of RayStateDev::ctr");
 constexpr int kSegPollMax = 1 << 20;                            // polls (~2 us each) before a wave gives a segment up: the exit every wave reaches
 constexpr unsigned kSegDone = 0xffu;                            // seg_flag: every ray of the group has left the volume
 
@@ -687,6 +691,9 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
                 __builtin_amdgcn_s_sleep(8);
             }
             if ((flag & 0xffu) == kSegDone) return;             // wave-uniform: no ray of this group is still in the volume
+#if PHOTON_SEG_ACQUIRE
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // belt and braces (off: see below)
+#endif
             // No agent-scope acquire here: every load of the handed-off words below is an sc1 load (bypasses this CU's L1),
             // every one of them was stored sc1 and drained before the flag, and the flag itself was polled sc1 -- the guide's
             // conditions for leaving the buffer_inv out, checked for exactly this pattern (lines shared between groups, five
@@ -701,7 +708,10 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
             } else {
                 const unsigned c = ld_agent(&st.ctr[r]);
                 marching = (c >> 31) != 0u;
-                rs.loop_ctr = (int)(c & 0x7fffffffu);
+                rs.loop_ctr = (int)(c & 0xffffffu);
+                // a ray still marching was written by the previous segment: its word says so (bits 24-30).  Anything else is
+                // a STALE word -- the hand-off broken -- and the render must not be returned (march_error_check)
+                if (marching && ((c >> 24) & 0x7fu) != ((seg - 1u) & 0x7fu)) atomicAdd(a->error, 1u);
                 rs.spins = (int)ld_agent(&st.spins[r]);
                 if (INTERP == 1) {
                     const size_t n = st.stride;
@@ -744,7 +754,7 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
                 st_agent(&st.dx[r], d.x); st_agent(&st.dy[r], d.y); st_agent(&st.dz[r], d.z);
             }
             if (fresh ? has_ray : marching) {
-                st_agent(&st.ctr[r], (lane_of(still) ? 0x80000000u : 0u) | (unsigned)rs.loop_ctr);
+                st_agent(&st.ctr[r], (lane_of(still) ? 0x80000000u : 0u) | ((seg & 0x7fu) << 24) | ((unsigned)rs.loop_ctr & 0xffffffu));
                 st_agent(&st.spins[r], (unsigned)rs.spins);
                 if (INTERP == 1) {
                     const size_t n = st.stride;
@@ -2360,7 +2370,8 @@ static int march_error_check(photon_scene *scene) {
     unsigned e = 0;
     PH_CHECK(hipMemcpy(&e, scene->d_error, sizeof e, hipMemcpyDeviceToHost));
     if (!e) return 0;
-    fprintf(stderr, "photon: %u march waves gave up waiting for the previous segment of their group: this render is incomplete\n", e);
+    fprintf(stderr, "photon: %u hand-off errors between the segments of a march (a wave gave up waiting for the previous segment of its group, "
+                    "or read a stale ray state): this render is not valid\n", e);
     PH_CHECK(hipMemset(scene->d_error, 0, sizeof e));
     return 1;
 }
