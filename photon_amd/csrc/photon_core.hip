@@ -646,9 +646,9 @@ constexpr unsigned kSegDone = 0xffu;                            // seg_flag: eve
 //
 // SEGMENTS (round 4).  A group marches for ~1.9 ms whatever the launch, and a launch ends when its LAST group does: the
 // waves finish one by one over the final ~0.8 group times while the rest of the chip idles (measured with the wave-timing
-// profile: span - mean end; 1.6 ms of a 9.5 ms launch of one GPU's eighth of the headline job, the same 1.6 ms of the full
-// job's 60).  Cutting every march into S segments handed out breadth-first (all first segments, then all second ones, ...)
-// makes the quantum S times smaller and the drain with it; the state a ray carries between segments is the loops' own
+// profile: span - mean end; 1.4 ms of a 8.8 ms launch of one GPU's eighth of the headline job, the same 1.4 ms of the full
+// job's 59).  Cutting every march into S segments handed out breadth-first (all first segments, then all second ones, ...)
+// makes the quantum smaller and the drain with it (how many pieces, how long: plan_segments); the state a ray carries between segments is the loops' own
 // (MarchResume), so the bits do not change.  A segment's wave may have to wait for the wave still marching the previous
 // one (only when a launch has fewer groups than the chip holds waves: the host does not segment those): it polls the
 // group's flag, bounded -- a wave that gives up counts itself in MarchArgs::error and leaves (march_error_check).
