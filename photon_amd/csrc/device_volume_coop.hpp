@@ -58,6 +58,9 @@ __device__ __forceinline__ void path_stat(int, unsigned long long = 1) {}
 #define PHOTON_WEIGHT_FAST 0        // a one-instruction-shorter exact form of the fixed-point trilinear weights where the grid allows it
 #endif                              // (tex3d_linear_coop): bit-identical, and SLOWER -- RK4 469 -> 459, Euler 1092 -> 1080 Mrays/s on C3: the
                                     // wave-uniform branch costs these register-bound kernels more than three instructions save.  Off.
+#ifndef PHOTON_LINEAR_TILE_LAYERS
+#define PHOTON_LINEAR_TILE_LAYERS 16        // layers of the trilinear sampler's coherent tile: 4 / 8 / 16 (3 / 7 / 15 cells of a column) or 2 (one cell: rounds 1-3)
+#endif
 #ifndef PHOTON_TILE_LANE_PIN
 #define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch in the RK4 kernels (1) or left to the compiler (0)
 #endif
@@ -74,7 +77,16 @@ constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels betwee
 // per wave: the tile (64 texels reserved; trilinear uses 8) + the brick: 8x8x4 texels for the tricubic sampler, 8x8x2 for
 // the trilinear one -- 7 KiB against 4 KiB, i.e. at most 5 against 10 workgroups of four waves in a CU's 160 KiB
 // -- and, for the trilinear kernels, one more 16-byte slot per lane behind the brick: the last value the lane sampled (PrevStash)
-template <int INTERP> constexpr int wave_lds_texels() { return 64 + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 && PHOTON_PREV_STASH ? 64 : 0); }
+// Layers of the tricubic sampler's coherent tile: 4 (one cell: rounds 1-3) ... 8 (five cells of the column the wave travels
+// along).  C3, same box, march ms twice each: 4 layers 58.40 / 58.45, 6: 58.17 / 58.39, 7: 58.10 / 58.12, 8: 58.79 / 58.84 --
+// 8 KiB of LDS per wave, four waves per SIMD instead of five (and only 0.7 % slower for it: the kernel is not latency-bound).
+#ifndef PHOTON_CUBIC_TILE_LAYERS
+#define PHOTON_CUBIC_TILE_LAYERS 7
+#endif
+constexpr int kCubicTileLayers = PHOTON_CUBIC_TILE_LAYERS;
+static_assert(kCubicTileLayers >= 4 && kCubicTileLayers <= 8, "PHOTON_CUBIC_TILE_LAYERS");
+template <int INTERP> constexpr int tile_texels() { return INTERP == 2 ? 16 * kCubicTileLayers : 64; }
+template <int INTERP> constexpr int wave_lds_texels() { return tile_texels<INTERP>() + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 && PHOTON_PREV_STASH ? 64 : 0); }
 constexpr int kPrevStashOffset = 64 + 2 * kBrickSlab;           // texel slot of lane 0's stash in a trilinear wave's LDS area
 constexpr int kWaveLdsTexels = wave_lds_texels<2>();
 
@@ -327,6 +339,39 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
     return acc;
 }
 
+#ifndef PHOTON_ABLATE_SGPR_CHAIN
+#define PHOTON_ABLATE_SGPR_CHAIN 0  // MEASUREMENT ONLY (wrong numbers): the coherent chain as 256 plain multiply-adds whose texel operand is an SGPR --
+#endif                              // no LDS read, no DPP form: the floor of a sampler that would bring its texels in through the scalar cache
+#if PHOTON_ABLATE_SGPR_CHAIN
+__device__ __forceinline__ f4 cubic_taps_ablate(const float (&wx)[4], const float (&wy)[4], const float (&wz)[4]) {
+    float wxy[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) wxy[b][a] = wx[a] * wy[b];
+    float tx, ty, tz, tw;                                       // every texel = (0, 0, 0, 0.01), opaque to the compiler, in SGPRs
+    asm volatile("s_mov_b32 %0, 0\n\ts_mov_b32 %1, 0\n\ts_mov_b32 %2, 0\n\ts_mov_b32 %3, 0x3c23d70a" : "=s"(tx), "=s"(ty), "=s"(tz), "=s"(tw));
+    f4 acc = f4{0, 0, 0, 0}, s = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int b = r & 3, c = r >> 2;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const float w = wxy[b][a];
+            if (a == 0 && b == 0) s = f4{w * tx, w * ty, w * tz, w * tw};
+            else s = f4{fmaf(w, tx, s.x), fmaf(w, ty, s.y), fmaf(w, tz, s.z), fmaf(w, tw, s.w)};
+            asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w), "+s"(tx), "+s"(ty), "+s"(tz), "+s"(tw));
+        }
+        if (b == 3) {
+            if (c == 0) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
+            else acc = f4{fmaf(wz[c], s.x, acc.x), fmaf(wz[c], s.y, acc.y), fmaf(wz[c], s.z, acc.z), fmaf(wz[c], s.w, acc.w)};
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));
+        }
+    }
+    return acc;
+}
+#endif
+
 // Lane predicates of the march are kept as WAVE MASKS (64-bit, wave-uniform, SGPR pairs): a mask comes out of
 // ballot(one comparison) -- a single v_cmp writing an SGPR pair -- and masks combine with integer & | ~ on the scalar
 // unit.  A predicate that is an AND / OR of i1 values reaches ballot() as a 0/1 VGPR instead (v_cndmask + v_cmp per use),
@@ -338,9 +383,12 @@ __device__ __forceinline__ bool lane_of(unsigned long long mask) { return __buil
 // samples of a ray advance by half a texel, so about every other sample finds its block / brick still there
 // and skips the fetch.  A block is named by the BIT PATTERNS of its three floor() values (readlane'd from its
 // leader): comparing those needs no float -> int conversion on the per-sample path.
-struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; };      // reg: z-slab 0 of the parked tile in registers (PHOTON_DPP_SLAB, per lane)
+// ti, tj, tk: the tricubic sampler's current CELL (the one the register slab belongs to), the trilinear sampler's column and
+// base layer.  ci, cj, k0, coff (tricubic, tiles deeper than one cell): the tile's column (bit patterns), the k of its first
+// cell, and the current cell's texel offset in it.
+struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; int ci, cj, k0, coff; };      // reg: z-slab 0 of the current cell in registers (PHOTON_DPP_SLAB, per lane)
 __device__ __forceinline__ Parked parked_none() {                // 0x7fffffff: a NaN pattern no floor() of a sampled coordinate has
-    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}};
+    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}, 0x7fffffff, 0x7fffffff, 0, 0};
 }
 
 // Block coherence of a wave's sample: the first sampling lane leads; the wave is coherent when every sampling lane
@@ -362,7 +410,7 @@ __device__ __forceinline__ unsigned long long same_block(const Lead &c, float fi
 // by a 256-texel brick.
 __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need,
                                                float x, float y, float z, Parked &parked) {
-    f4 *const brick = blk + 64;                                 // the wave's 8x8x4 brick follows its 4x4x4 tile
+    f4 *const brick = blk + tile_texels<2>();                   // the wave's 8x8x4 brick follows its tile
     const float xg = x - 0.5f, yg = y - 0.5f, zg = z - 0.5f;
     const float fi = floorf(xg), fj = floorf(yg), fk = floorf(zg);
     float wx[4], wy[4], wz[4];
@@ -371,6 +419,72 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
     const int lane = threadIdx.x & 63;
     if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
+#if PHOTON_CUBIC_TILE_LAYERS > 4
+    {
+        // COHERENT wave -- every sampling lane in ONE cell (BOS: always, except where a wave straddles two sources or a
+        // cone straddles a texel boundary).  The parked tile is 4 x 4 texels wide and TL layers deep: TL - 3 cells of the
+        // column the wave travels along (a ray advances a cell per RK4 iteration: the one-cell tile of rounds 1-3 was
+        // fetched 0.35 times per sample), lane l <-> texel (l&3, (l>>2)&3, l>>4) of every four layers, clamp-to-edge per
+        // texel.  The chain reads its cell with broadcast reads at the cell's offset in the tile; z-slab 0 of the CURRENT
+        // cell sits in registers (parked.reg) and is re-read from LDS when the wave moves on to the next cell of the
+        // tile.  The test is against the current cell first (no leader, no readlane); a wave that went to the bricks
+        // forgets its cell and skips that test while it stays incoherent.
+        constexpr int TL = kCubicTileLayers;
+        bool hit = false;
+        if (parked.ti != 0x7fffffff) {                          // wave-uniform
+            asm volatile("");
+            hit = ((ballot(__float_as_int(fi) == parked.ti) & ballot(__float_as_int(fj) == parked.tj) & ballot(__float_as_int(fk) == parked.tk)) & need) == need;
+        }
+        if (!hit) {
+            const Lead c = lead_of(need, fi, fj, fk);
+            if ((same_block(c, fi, fj, fk) & need) == need) {   // wave-uniform: one cell
+                const int ck = (int)__int_as_float(c.k);
+                int dz = ck - parked.k0;
+                if (c.i != parked.ci || c.j != parked.cj || (unsigned)dz > (unsigned)(TL - 4)) {      // not in the parked tile
+                    path_stat(1);
+                    const int ci = (int)__int_as_float(c.i), cj = (int)__int_as_float(c.j);
+                    // the tile starts at the wave's cell when it travels upwards (or nothing tells), ends there when downwards
+                    const bool down = c.i == parked.ci && c.j == parked.cj && dz < 0;
+                    const int k0 = down ? ck - (TL - 4) : ck;
+                    __builtin_amdgcn_wave_barrier();
+                    int l = lane;
+                    asm volatile("" : "+v"(l));                 // keep the tile's lane offsets out of the march loop's live registers
+                    const int tx = clampi(ci - 1 + (l & 3), 0, v.nx - 1), ty = clampi(cj - 1 + ((l >> 2) & 3), 0, v.ny - 1);
+#pragma unroll
+                    for (int j = 0; j < (TL + 3) / 4; j++) {
+                        if (TL % 4 == 0 || j < TL / 4 || l < 16 * (TL % 4)) {
+                            const int tz = clampi(k0 - 1 + (l >> 4) + 4 * j, 0, v.nz - 1);
+                            const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));      // < 2^31 texels (checked on the host)
+                            *reinterpret_cast<float4 *>(blk + l + 64 * j) = make_float4(t.x, t.y, t.z, t.w);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    parked.ci = c.i; parked.cj = c.j; parked.k0 = k0;
+                    dz = ck - k0;
+                }
+                parked.coff = dz * 16;
+                if (PHOTON_DPP_SLAB) parked.reg = ldtexel(blk + parked.coff + (lane & 15));   // slab 0 of the cell, into every 16-lane row
+                parked.ti = c.i; parked.tj = c.j; parked.tk = c.k;
+                hit = true;
+            }
+        }
+        if (hit) {
+            path_stat(0);
+            const f4 *cell = blk + parked.coff;
+#if PHOTON_ABLATE_SGPR_CHAIN == 2                                // MEASUREMENT ONLY: no chain at all (the weights kept alive): what everything else costs
+            const float wsum = ((wx[0] + wx[1]) + (wx[2] + wx[3])) + ((wy[0] + wy[1]) + (wy[2] + wy[3])) + ((wz[0] + wz[1]) + (wz[2] + wz[3]));
+            const f4 acc = f4{0, 0, 0, fmaf(wsum, 0.0f, 0.01f)};
+#elif PHOTON_ABLATE_SGPR_CHAIN
+            const f4 acc = cubic_taps_ablate(wx, wy, wz);
+#else
+            const f4 acc = PHOTON_DPP_SLAB ? cubic_taps_hybrid(cell, parked.reg, wx, wy, wz) : cubic_taps_lds<4, 16>(cell, wx, wy, wz);
+#endif
+            __builtin_amdgcn_wave_barrier();
+            return acc;
+        }
+        parked.ti = 0x7fffffff;                                 // to the bricks: the cell is forgotten (the tile stays)
+    }
+#else
     {
         // COHERENT wave -- every sampling lane wants the block of the first one (BOS: always, except where a
         // wave straddles two sources or a cone straddles a texel boundary): one load instruction for the
@@ -397,6 +511,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
             return acc;
         }
     }
+#endif
     // INCOHERENT wave (full-aperture cones, source boundaries: the lanes' blocks form a patch a few texels wide
     // in one z-slab).  Serving it group by group would cost the whole wave one chain per distinct block.
     // Instead: park the 8x8x4 BRICK around the first unserved lane's block -- four loads per lane -- and let
@@ -456,6 +571,17 @@ __device__ __attribute__((noinline)) f4 linear_gather_fn(const f4 *__restrict__ 
                              quant_weight(yb - fj, weight_scale, weight_inv), quant_weight(zb - fk, weight_scale, weight_inv));
 }
 
+// Inline asm on purpose: the builtin is folded away when the compiler can prove its operand uniform,
+// which leaves a VALU-computed float (cvt, div) in a VGPR for the whole loop -- or in scratch.
+// The s_nops cover the gfx940+ hazards the compiler cannot see through inline asm (VALU writes VGPR ->
+// readlane reads it: 1 wait state; VALU writes SGPR -> VALU / VMEM reads it: 2 / 5 wait states); this
+// runs once per kernel, in the prologue.
+__device__ __forceinline__ float uniformf(float x) {
+    float s;
+    asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(s) : "v"(x));
+    return s;
+}
+
 // v of the neighbouring lane of the pair (lane ^ 1): one DPP move, no LDS round trip
 __device__ __forceinline__ float pair_swap(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false));
@@ -488,6 +614,77 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     }
     const int lane = threadIdx.x & 63;
     if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
+#if PHOTON_LINEAR_TILE_LAYERS >= 4
+    {
+        constexpr int TL = PHOTON_LINEAR_TILE_LAYERS;                // layers of the tile: TL - 1 cells of a column
+        static_assert(TL == 4 || TL == 8 || TL == 16, "PHOTON_LINEAR_TILE_LAYERS");
+        // coherent wave: ONE column of cells serves everybody.  The parked tile is 2 x 2 texels wide and TL layers deep --
+        // TL - 1 cells of the column the wave is travelling along (a ray advances one cell per RK4 iteration, so the 2x2x2
+        // tile of rounds 1-3 was fetched about once per iteration, 0.34 fetches per sample on C3, and the kernel waits on
+        // each: 0.05 with sixteen layers) -- fetched by lanes 0 .. 4 TL - 1 with one load instruction and parked as
+        // (texel, x-difference) pairs: slot 4 L + 2 b = texel (0, b, L), slot 4 L + 2 b + 1 = texel (1, b, L) - texel
+        // (0, b, L) -- the subtraction every lane's first-level lerp fmaf(a, t1 - t0, t0) would repeat on identical operands
+        // is done once per tile by the fetching lane (same f32 operation, same bits).  A lane whose cell is dz layers above
+        // the tile's base blends from slot 4 dz on, each lane reading its own addresses: the lanes of a wave that is
+        // crossing a layer boundary are served together.  The test is against the PARKED tile (no leader, no readlane, on
+        // the common path): same column -- the bit patterns of two floor() values -- and dz = fk - base in 0 .. TL - 2, by
+        // conversion (a negative difference converts to a large unsigned value; with four layers dz is read off the
+        // difference's bit pattern instead -- 0, 0x3f800000, 0x40000000: one unsigned compare, the top three bits ARE dz).
+        // A wave that went to the bricks forgets its tile (parked.ti = none, below): while it stays incoherent it skips this
+        // test (a scalar branch; the empty asm keeps the compiler from turning it into unconditional vector code).
+        constexpr unsigned kDzMax = TL == 4 ? 0x40000000u : (unsigned)(TL - 2);
+        unsigned dzb = 0;
+        bool hit = false;
+        if (parked.ti != 0x7fffffff) {                          // wave-uniform
+            asm volatile("");
+            dzb = TL == 4 ? __float_as_uint(fk - __int_as_float(parked.tk)) : (unsigned)(int)(fk - __int_as_float(parked.tk));
+            hit = ((ballot(__float_as_int(fi) == parked.ti) & ballot(__float_as_int(fj) == parked.tj) & ballot(dzb <= kDzMax)) & need) == need;
+        }
+        if (!hit) {                                             // wave-uniform
+            const Lead ld = lead_of(need, fi, fj, fk);
+            if (((ballot(__float_as_int(fi) == ld.i) & ballot(__float_as_int(fj) == ld.j)) & need) == need) {       // one column
+                path_stat(1);
+                // where the tile starts: the leader's layer when the wave travels upwards (or nothing tells: first fetch, new
+                // column), two below it when downwards -- the tile parked before says which --, shifted by one when lanes
+                // of the wave sit on the other side of the leader (a wave crossing a layer boundary)
+                const float klf = __int_as_float(ld.k), pkf = __int_as_float(parked.tk);
+                const bool behind = (need & ballot(fk < klf)) != 0, ahead = (need & ballot(fk > klf)) != 0;
+                const bool down = ld.i == parked.ti && ld.j == parked.tj && klf < pkf;
+                const int ci = (int)__int_as_float(ld.i), cj = (int)__int_as_float(ld.j);
+                const int base = (int)klf - (down ? (ahead ? TL - 3 : TL - 2) : (behind ? 1 : 0));
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 4 * TL) {
+                    int l = lane;
+                    if (PIN && PHOTON_TILE_LANE_PIN) asm volatile("" : "+v"(l));       // keep the tile's lane offsets out of the march loop's live
+                                                                // registers: hoisted as loop invariants they were spilled, every fetch reloading them
+                    const int tx = clampi(ci + (l & 1), 0, v.nx - 1), ty = clampi(cj + ((l >> 1) & 1), 0, v.ny - 1),
+                              tz = clampi(base + (l >> 2), 0, v.nz - 1);
+                    const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+                    const f4 o = f4{pair_swap(t.x), pair_swap(t.y), pair_swap(t.z), pair_swap(t.w)};     // the pair's other texel
+                    const bool hi = (l & 1) != 0;
+                    *reinterpret_cast<float4 *>(blk + l) = make_float4(hi ? t.x - o.x : t.x, hi ? t.y - o.y : t.y,
+                                                                       hi ? t.z - o.z : t.z, hi ? t.w - o.w : t.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const float basef = uniformf((float)base);
+                parked.ti = ld.i; parked.tj = ld.j; parked.tk = __float_as_int(basef);
+                dzb = TL == 4 ? __float_as_uint(fk - basef) : (unsigned)(int)(fk - basef);
+                hit = (ballot(dzb <= kDzMax) & need) == need;           // else: lanes more than TL - 1 layers apart
+            }
+        }
+        if (hit) {
+            path_stat(0);
+            // q[tc*4 + tb*2 + {0: texel, 1: x-difference}], q = the lane's cell in the tile; same lerp tree as tex3d_linear
+            const f4 *q = blk + ((TL == 4 ? dzb >> 29 : (dzb & (unsigned)(TL - 1))) << 2);     // (the mask: lanes that do not sample stay inside the tile)
+            const f4 c00 = lerp4d(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4d(ldtexel(q + 2), ldtexel(q + 3), a);
+            const f4 c01 = lerp4d(ldtexel(q + 4), ldtexel(q + 5), a), c11 = lerp4d(ldtexel(q + 6), ldtexel(q + 7), a);
+            const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
+            const f4 acc = lerp4(c0, c1, c);
+            __builtin_amdgcn_wave_barrier();
+            return acc;
+        }
+    }
+#else
     {
         // coherent wave: the 2x2x2 block of the first sampling lane serves everybody.  Lanes 0-7 fetch it and park it
         // as four (texel, x-difference) pairs: slot 2p = texel (0,b,c), slot 2p+1 = texel (1,b,c) - texel (0,b,c) --
@@ -496,7 +693,9 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         // The blend runs on every lane, unpredicated (see tex3d_cubic_coop).
         const Lead ld = lead_of(need, fi, fj, fk);
         if ((same_block(ld, fi, fj, fk) & need) == need) {      // wave-uniform
+            path_stat(0);
             if (!PHOTON_TILE_REUSE || ld.i != parked.ti || ld.j != parked.tj || ld.k != parked.tk) {  // wave-uniform: not parked yet
+                path_stat(1);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 8) {
                     int l = lane;
@@ -523,12 +722,17 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
             return acc;
         }
     }
+#endif
     // incoherent wave: bricks of 8x8x2 texels around the first unserved lane (two loads per lane); every lane
     // whose block starts within [-3, +3] texels of it in x and y (same z) blends from there in one pass
     const int bi = (int)fi, bj = (int)fj, bk = (int)fk;
     f4 acc = f4{0, 0, 0, 0};
     bool done = !lane_of(need);
     unsigned long long todo = need;
+    path_stat(2);
+#if PHOTON_LINEAR_TILE_LAYERS >= 4
+    parked.ti = 0x7fffffff;                                     // the tile is forgotten (see the test above)
+#endif
 #pragma unroll 1
     for (int pass = 0; pass < PHOTON_BRICK_PASSES && todo != 0; pass++) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -536,7 +740,10 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                   ck = __builtin_amdgcn_readlane(bk, leader);
         const int di = bi - ci + 3, dj = bj - cj + 3;
         const bool in_brick = !done && bk == ck && (unsigned)di <= 6u && (unsigned)dj <= 6u;
+        path_stat(3);
+        path_stat(6, (unsigned long long)__popcll(ballot(in_brick)));
         if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
+            path_stat(4);
             __builtin_amdgcn_wave_barrier();
             int l = lane;
             asm volatile("" : "+v"(l));
@@ -564,6 +771,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         __builtin_amdgcn_wave_barrier();
         todo = ballot(!done);
     }
+    path_stat(5, (unsigned long long)__popcll(ballot(!done)));
     if (!done) acc = linear_gather_fn(tex, v.nx, v.ny, v.nz, x, y, z, v.weight_scale, v.weight_inv);
     return acc;
 }
@@ -579,16 +787,6 @@ struct MarchU {
     float step, data_min, spin_step;            // h, min(n-1), h / (1 + data_min)
     int nx, ny, nz;
 };
-// Inline asm on purpose: the builtin is folded away when the compiler can prove its operand uniform,
-// which leaves a VALU-computed float (cvt, div) in a VGPR for the whole loop -- or in scratch.
-// The s_nops cover the gfx940+ hazards the compiler cannot see through inline asm (VALU writes VGPR ->
-// readlane reads it: 1 wait state; VALU writes SGPR -> VALU / VMEM reads it: 2 / 5 wait states); this
-// runs once per kernel, in the prologue.
-__device__ __forceinline__ float uniformf(float x) {
-    float s;
-    asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(s) : "v"(x));
-    return s;
-}
 __device__ __forceinline__ MarchU make_march_consts(const VolumeDev &v, f3 scale) {
     MarchU u;
     u.minx = uniformf(v.min_bound.x); u.miny = uniformf(v.min_bound.y); u.minz = uniformf(v.min_bound.z);
