@@ -61,6 +61,15 @@ __device__ __forceinline__ void path_stat(int, unsigned long long = 1) {}
 #ifndef PHOTON_LINEAR_TILE_LAYERS
 #define PHOTON_LINEAR_TILE_LAYERS 16        // layers of the trilinear sampler's coherent tile: 4 / 8 / 16 (3 / 7 / 15 cells of a column) or 2 (one cell: rounds 1-3)
 #endif
+#ifndef PHOTON_LINEAR_TILES
+#define PHOTON_LINEAR_TILES 2       // tiles the trilinear sampler parks per wave: 2 = a wave across two columns (two light sources) is served like a coherent one
+#endif
+#ifndef PHOTON_TILE_RETRY_MASK
+#define PHOTON_TILE_RETRY_MASK 15  // an incoherent wave tries its tiles again on the trips of the march loop whose number & mask == 0
+#endif
+#ifndef PHOTON_REPAIR_INLINE
+#define PHOTON_REPAIR_INLINE 0
+#endif
 #ifndef PHOTON_TILE_LANE_PIN
 #define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch in the RK4 kernels (1) or left to the compiler (0)
 #endif
@@ -85,9 +94,9 @@ constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels betwee
 #endif
 constexpr int kCubicTileLayers = PHOTON_CUBIC_TILE_LAYERS;
 static_assert(kCubicTileLayers >= 4 && kCubicTileLayers <= 8, "PHOTON_CUBIC_TILE_LAYERS");
-template <int INTERP> constexpr int tile_texels() { return INTERP == 2 ? 16 * kCubicTileLayers : 64; }
+template <int INTERP> constexpr int tile_texels() { return INTERP == 2 ? 16 * kCubicTileLayers : (PHOTON_LINEAR_TILE_LAYERS >= 4 && PHOTON_LINEAR_TILES * PHOTON_LINEAR_TILE_LAYERS * 4 > 64 ? PHOTON_LINEAR_TILES * PHOTON_LINEAR_TILE_LAYERS * 4 : 64); }
 template <int INTERP> constexpr int wave_lds_texels() { return tile_texels<INTERP>() + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 && PHOTON_PREV_STASH ? 64 : 0); }
-constexpr int kPrevStashOffset = 64 + 2 * kBrickSlab;           // texel slot of lane 0's stash in a trilinear wave's LDS area
+constexpr int kPrevStashOffset = tile_texels<1>() + 2 * kBrickSlab;           // texel slot of lane 0's stash in a trilinear wave's LDS area
 constexpr int kWaveLdsTexels = wave_lds_texels<2>();
 
 // 64-tap sum (slab order) over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
@@ -384,11 +393,11 @@ __device__ __forceinline__ bool lane_of(unsigned long long mask) { return __buil
 // and skips the fetch.  A block is named by the BIT PATTERNS of its three floor() values (readlane'd from its
 // leader): comparing those needs no float -> int conversion on the per-sample path.
 // ti, tj, tk: the tricubic sampler's current CELL (the one the register slab belongs to), the trilinear sampler's column and
-// base layer.  ci, cj, k0, coff (tricubic, tiles deeper than one cell): the tile's column (bit patterns), the k of its first
+// base layer (tile A; ui, uj, uk: tile B).  ci, cj, k0, coff (tricubic, tiles deeper than one cell): the tile's column (bit patterns), the k of its first
 // cell, and the current cell's texel offset in it.
-struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; int ci, cj, k0, coff; };      // reg: z-slab 0 of the current cell in registers (PHOTON_DPP_SLAB, per lane)
+struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; int ci, cj, k0, coff; int ui, uj, uk; };      // reg: z-slab 0 of the current cell in registers (PHOTON_DPP_SLAB, per lane)
 __device__ __forceinline__ Parked parked_none() {                // 0x7fffffff: a NaN pattern no floor() of a sampled coordinate has
-    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}, 0x7fffffff, 0x7fffffff, 0, 0};
+    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}, 0x7fffffff, 0x7fffffff, 0, 0, 0x7fffffff, 0x7fffffff, 0x7fffffff};
 }
 
 // Block coherence of a wave's sample: the first sampling lane leads; the wave is coherent when every sampling lane
@@ -591,8 +600,8 @@ __device__ __forceinline__ float pair_swap(float v) {
 // it -- as a run-time select per weight it cost three v_cndmask per sample).
 template <bool QUANT, bool PIN = false>
 __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need,
-                                                float x, float y, float z, Parked &parked) {
-    f4 *const brick = blk + 64;                                 // 8x8x2 texels around the leader for incoherent waves
+                                                float x, float y, float z, Parked &parked, unsigned tick = 0) {
+    f4 *const brick = blk + tile_texels<1>();                   // 8x8x2 texels around the leader for incoherent waves
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
     float a = xb - fi, b = yb - fj, c = zb - fk;
@@ -616,9 +625,11 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
 #if PHOTON_LINEAR_TILE_LAYERS >= 4
     {
-        constexpr int TL = PHOTON_LINEAR_TILE_LAYERS;                // layers of the tile: TL - 1 cells of a column
+        constexpr int TL = PHOTON_LINEAR_TILE_LAYERS;                // layers of a tile: TL - 1 cells of a column
+        constexpr int NT = PHOTON_LINEAR_TILES;                      // tiles parked per wave
         static_assert(TL == 4 || TL == 8 || TL == 16, "PHOTON_LINEAR_TILE_LAYERS");
-        // coherent wave: ONE column of cells serves everybody.  The parked tile is 2 x 2 texels wide and TL layers deep --
+        static_assert(NT == 1 || NT == 2, "PHOTON_LINEAR_TILES");
+        // coherent wave: ONE column of cells serves everybody.  A parked tile is 2 x 2 texels wide and TL layers deep --
         // TL - 1 cells of the column the wave is travelling along (a ray advances one cell per RK4 iteration, so the 2x2x2
         // tile of rounds 1-3 was fetched about once per iteration, 0.34 fetches per sample on C3, and the kernel waits on
         // each: 0.05 with sixteen layers) -- fetched by lanes 0 .. 4 TL - 1 with one load instruction and parked as
@@ -628,54 +639,103 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         // the tile's base blends from slot 4 dz on, each lane reading its own addresses: the lanes of a wave that is
         // crossing a layer boundary are served together.  The test is against the PARKED tile (no leader, no readlane, on
         // the common path): same column -- the bit patterns of two floor() values -- and dz = fk - base in 0 .. TL - 2, by
-        // conversion (a negative difference converts to a large unsigned value; with four layers dz is read off the
-        // difference's bit pattern instead -- 0, 0x3f800000, 0x40000000: one unsigned compare, the top three bits ARE dz).
-        // A wave that went to the bricks forgets its tile (parked.ti = none, below): while it stays incoherent it skips this
-        // test (a scalar branch; the empty asm keeps the compiler from turning it into unconditional vector code).
-        constexpr unsigned kDzMax = TL == 4 ? 0x40000000u : (unsigned)(TL - 2);
-        unsigned dzb = 0;
+        // conversion (a negative difference converts to a large unsigned value).
+        // TWO tiles are parked (A, and B right behind it in LDS): a wave whose lanes sit in two columns -- the last rays of
+        // one light source and the first of the next (one wave in eight on C3), a cone across a cell boundary -- is served
+        // like a coherent one, each lane blending from its column's tile; only when the first test fails is the second made.
+        // A wave that has to go to the bricks (three columns or more) forgets its tiles and marks itself incoherent (ui =
+        // kIncoherent): it then goes straight to the bricks, trying its tiles again only on every sixteenth trip of the
+        // march loop (`tick`: a counter the loop keeps anyway -- the bookkeeping takes no register, and the trilinear
+        // kernels have none to spare: with two more scalars for a pause counter RK4 on C3 ran 4 % slower).  A wave of
+        // full-aperture cones (C5: never coherent) pays a scalar compare and branch per sample for the tiles it cannot
+        // use.  (The empty asm keeps the compiler from turning the scalar branch around the first test into
+        // unconditional vector code.)
+        constexpr unsigned kDzMax = (unsigned)(TL - 2);
+        constexpr int kIncoherent = 0x7ffffffe;                 // another NaN pattern
+        const int fib = __float_as_int(fi), fjb = __float_as_int(fj);
+        unsigned dzq = 0;                                       // the lane's layer offset in the tile area (tile B: + TL)
+        unsigned long long ok_a = 0, ok_b = 0;                  // lanes whose cell lies in tile A / B
         bool hit = false;
         if (parked.ti != 0x7fffffff) {                          // wave-uniform
             asm volatile("");
-            dzb = TL == 4 ? __float_as_uint(fk - __int_as_float(parked.tk)) : (unsigned)(int)(fk - __int_as_float(parked.tk));
-            hit = ((ballot(__float_as_int(fi) == parked.ti) & ballot(__float_as_int(fj) == parked.tj) & ballot(dzb <= kDzMax)) & need) == need;
-        }
-        if (!hit) {                                             // wave-uniform
-            const Lead ld = lead_of(need, fi, fj, fk);
-            if (((ballot(__float_as_int(fi) == ld.i) & ballot(__float_as_int(fj) == ld.j)) & need) == need) {       // one column
-                path_stat(1);
-                // where the tile starts: the leader's layer when the wave travels upwards (or nothing tells: first fetch, new
-                // column), two below it when downwards -- the tile parked before says which --, shifted by one when lanes
-                // of the wave sit on the other side of the leader (a wave crossing a layer boundary)
-                const float klf = __int_as_float(ld.k), pkf = __int_as_float(parked.tk);
-                const bool behind = (need & ballot(fk < klf)) != 0, ahead = (need & ballot(fk > klf)) != 0;
-                const bool down = ld.i == parked.ti && ld.j == parked.tj && klf < pkf;
-                const int ci = (int)__int_as_float(ld.i), cj = (int)__int_as_float(ld.j);
-                const int base = (int)klf - (down ? (ahead ? TL - 3 : TL - 2) : (behind ? 1 : 0));
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 4 * TL) {
-                    int l = lane;
-                    if (PIN && PHOTON_TILE_LANE_PIN) asm volatile("" : "+v"(l));       // keep the tile's lane offsets out of the march loop's live
-                                                                // registers: hoisted as loop invariants they were spilled, every fetch reloading them
-                    const int tx = clampi(ci + (l & 1), 0, v.nx - 1), ty = clampi(cj + ((l >> 1) & 1), 0, v.ny - 1),
-                              tz = clampi(base + (l >> 2), 0, v.nz - 1);
-                    const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-                    const f4 o = f4{pair_swap(t.x), pair_swap(t.y), pair_swap(t.z), pair_swap(t.w)};     // the pair's other texel
-                    const bool hi = (l & 1) != 0;
-                    *reinterpret_cast<float4 *>(blk + l) = make_float4(hi ? t.x - o.x : t.x, hi ? t.y - o.y : t.y,
-                                                                       hi ? t.z - o.z : t.z, hi ? t.w - o.w : t.w);
+            dzq = (unsigned)(int)(fk - __int_as_float(parked.tk));
+            ok_a = ballot(fib == parked.ti) & ballot(fjb == parked.tj) & ballot(dzq <= kDzMax);
+            hit = (ok_a & need) == need;
+            if (NT == 2 && !hit && parked.ui < kIncoherent) {   // wave-uniform
+                const unsigned dzu = (unsigned)(int)(fk - __int_as_float(parked.uk));
+                ok_b = ballot(fib == parked.ui) & ballot(fjb == parked.uj) & ballot(dzu <= kDzMax);
+                if (((ok_a | ok_b) & need) == need) {
+                    hit = true;
+                    dzq = lane_of(ok_a) ? dzq : dzu + TL;
                 }
-                __builtin_amdgcn_wave_barrier();
-                const float basef = uniformf((float)base);
-                parked.ti = ld.i; parked.tj = ld.j; parked.tk = __float_as_int(basef);
-                dzb = TL == 4 ? __float_as_uint(fk - basef) : (unsigned)(int)(fk - basef);
-                hit = (ballot(dzb <= kDzMax) & need) == need;           // else: lanes more than TL - 1 layers apart
+            }
+        }
+        if (!hit && (parked.ui != kIncoherent || (tick & (unsigned)PHOTON_TILE_RETRY_MASK) == 0)) {      // wave-uniform: some sampling lanes have no tile
+            // the columns of the lanes without a tile: at most as many as there are tiles that serve nobody
+            const unsigned long long rest = need & ~(ok_a | ok_b);
+            const Lead l1 = lead_of(rest, fi, fj, fk);
+            const unsigned long long col1 = rest & ballot(fib == l1.i) & ballot(fjb == l1.j), rest2 = rest & ~col1;
+            Lead l2 = l1;
+            unsigned long long col2 = 0;
+            int n_new = 1;
+            if (rest2 != 0) {
+                l2 = lead_of(rest2, fi, fj, fk);
+                col2 = rest2 & ballot(fib == l2.i) & ballot(fjb == l2.j);
+                n_new = (rest2 & ~col2) != 0 ? 3 : 2;
+            }
+            const bool free_a = (ok_a & need) == 0, free_b = NT == 2 && (ok_b & need) == 0;
+            if (n_new <= (free_a ? 1 : 0) + (free_b ? 1 : 0)) {
+#pragma unroll 1
+                for (int j = 0; j < n_new; j++) {
+                    path_stat(1);
+                    const bool to_a = j == 0 && free_a;         // the second new tile always goes to B
+                    const Lead ld = j == 0 ? l1 : l2;
+                    const unsigned long long lanes = j == 0 ? col1 : col2;
+                    // where the tile starts: the leader's layer when the wave travels upwards (or nothing tells: first fetch,
+                    // new column), TL - 2 below it when downwards -- the tile this one replaces says which --, shifted by
+                    // one when lanes of the column sit on the other side of the leader (a wave crossing a layer boundary)
+                    const int oi = to_a ? parked.ti : parked.ui, oj = to_a ? parked.tj : parked.uj, ok = to_a ? parked.tk : parked.uk;
+                    const float klf = __int_as_float(ld.k);
+                    const bool behind = (lanes & ballot(fk < klf)) != 0, ahead = (lanes & ballot(fk > klf)) != 0;
+                    const bool down = ld.i == oi && ld.j == oj && klf < __int_as_float(ok);
+                    const int ci = (int)__int_as_float(ld.i), cj = (int)__int_as_float(ld.j);
+                    const int base = (int)klf - (down ? (ahead ? TL - 3 : TL - 2) : (behind ? 1 : 0));
+                    f4 *const tile = blk + (to_a ? 0 : 4 * TL);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 4 * TL) {
+                        int l = lane;
+                        if (PIN && PHOTON_TILE_LANE_PIN) asm volatile("" : "+v"(l));   // keep the tile's lane offsets out of the march loop's live
+                                                                // registers: hoisted as loop invariants they were spilled, every fetch reloading them
+                        const int tx = clampi(ci + (l & 1), 0, v.nx - 1), ty = clampi(cj + ((l >> 1) & 1), 0, v.ny - 1),
+                                  tz = clampi(base + (l >> 2), 0, v.nz - 1);
+                        const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
+                        const f4 o = f4{pair_swap(t.x), pair_swap(t.y), pair_swap(t.z), pair_swap(t.w)};     // the pair's other texel
+                        const bool hi = (l & 1) != 0;
+                        *reinterpret_cast<float4 *>(tile + l) = make_float4(hi ? t.x - o.x : t.x, hi ? t.y - o.y : t.y,
+                                                                            hi ? t.z - o.z : t.z, hi ? t.w - o.w : t.w);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int basef = __float_as_int(uniformf((float)base));
+                    if (to_a) { parked.ti = ld.i; parked.tj = ld.j; parked.tk = basef; }
+                    else { parked.ui = ld.i; parked.uj = ld.j; parked.uk = basef; }
+                }
+                // every sampling lane's column is parked now; its layer may still be out of reach (lanes of one column
+                // more than TL - 1 layers apart): then the bricks serve the wave
+                dzq = (unsigned)(int)(fk - __int_as_float(parked.tk));
+                ok_a = ballot(fib == parked.ti) & ballot(fjb == parked.tj) & ballot(dzq <= kDzMax);
+                if (NT == 2 && parked.ui < kIncoherent) {
+                    const unsigned dzu = (unsigned)(int)(fk - __int_as_float(parked.uk));
+                    ok_b = ballot(fib == parked.ui) & ballot(fjb == parked.uj) & ballot(dzu <= kDzMax);
+                    dzq = lane_of(ok_a) ? dzq : dzu + TL;
+                }
+                hit = ((ok_a | ok_b) & need) == need;
+                if (hit && parked.ui == kIncoherent) parked.ui = 0x7fffffff;     // coherent again
             }
         }
         if (hit) {
             path_stat(0);
-            // q[tc*4 + tb*2 + {0: texel, 1: x-difference}], q = the lane's cell in the tile; same lerp tree as tex3d_linear
-            const f4 *q = blk + ((TL == 4 ? dzb >> 29 : (dzb & (unsigned)(TL - 1))) << 2);     // (the mask: lanes that do not sample stay inside the tile)
+            // q[tc*4 + tb*2 + {0: texel, 1: x-difference}], q = the lane's cell in its tile; same lerp tree as tex3d_linear
+            const f4 *q = blk + ((dzq & (unsigned)(NT * TL - 1)) << 2);         // (the mask: lanes that do not sample stay inside the wave's LDS area)
             const f4 c00 = lerp4d(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4d(ldtexel(q + 2), ldtexel(q + 3), a);
             const f4 c01 = lerp4d(ldtexel(q + 4), ldtexel(q + 5), a), c11 = lerp4d(ldtexel(q + 6), ldtexel(q + 7), a);
             const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
@@ -683,6 +743,8 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
             __builtin_amdgcn_wave_barrier();
             return acc;
         }
+        parked.ti = 0x7fffffff;                                 // to the bricks: the tiles are forgotten
+        parked.ui = kIncoherent;
     }
 #else
     {
@@ -730,9 +792,6 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     bool done = !lane_of(need);
     unsigned long long todo = need;
     path_stat(2);
-#if PHOTON_LINEAR_TILE_LAYERS >= 4
-    parked.ti = 0x7fffffff;                                     // the tile is forgotten (see the test above)
-#endif
 #pragma unroll 1
     for (int pass = 0; pass < PHOTON_BRICK_PASSES && todo != 0; pass++) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -852,8 +911,8 @@ struct PrevVal {                                                // A/B form: the
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
 template <int INTERP, bool QUANT, class CNT, bool PIN = false>
 __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restrict__ tex, f4 *blk, unsigned long long need, f3 lookup,
-                                          const PrevVal &prev, float data_min, CNT &mc, Parked &parked) {
-    f4 val = INTERP == 1 ? tex3d_linear_coop<QUANT, PIN>(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked)
+                                          const PrevVal &prev, float data_min, CNT &mc, Parked &parked, unsigned tick = 0) {
+    f4 val = INTERP == 1 ? tex3d_linear_coop<QUANT, PIN>(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked, tick)
                          : tex3d_cubic_coop(v, tex, blk, need, lookup.x, lookup.y, lookup.z, parked);
     count_samples(mc, need);
     if (INTERP == 1) {
@@ -862,11 +921,21 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
             const float ambient = 1.000277;
             const f4 val_prev = prev.get();                     // the lane's last sampled value (parked in LDS)
             const unsigned long long repair = low & ballot(val_prev.w == 0);
+#if PHOTON_REPAIR_INLINE
             if (repair != 0) {
                 const f4 t = tex3d_linear_coop<QUANT, PIN>(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
                 count_samples(mc, repair);
                 if (lane_of(repair)) val = f4{t.x, t.y, t.z, ambient - 1};
             }
+#else
+            if (repair != 0) {                                  // per lane, out of line: the same blend (the cooperative sampler's
+                count_samples(mc, repair);                      // own fallback), not a fourth copy of that sampler in the loop
+                if (lane_of(repair)) {
+                    const f4 t = linear_gather_fn(tex, v.nx, v.ny, v.nz, lookup.x, lookup.y, lookup.z - 1, v.weight_scale, v.weight_inv);
+                    val = f4{t.x, t.y, t.z, ambient - 1};
+                }
+            }
+#endif
             if (lane_of(low & ~repair)) val = val_prev;
         }
     }
@@ -945,7 +1014,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
             go = alive & access;
             spin = alive & ~access;                             // the reference's `continue`: step forward, retry next trip
         }
-        f4 val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
+        f4 val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked, trips);
         if (INTERP == 2) {                                      // .h:1220-1227
             const unsigned long long low = go & ballot(val.w < u.data_min);
             spin |= low;
@@ -972,7 +1041,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         unsigned long long in = inside_mask(spos, u);           // .h:1094-1101: outside = `break`, nothing committed
         active &= ~go | in;
         go &= in;
-        val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
+        val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked, trips);
         const float n_b = val.w + 1;
         const f3 B = delta_t * mk3(n_b * val.x, n_b * val.y, n_b * val.z);
         spos = rpos + delta_t * T_n + (0.5f * delta_t) * B;                     // .h:1131
@@ -982,7 +1051,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         in = inside_mask(spos, u);                              // .h:1135-1141
         active &= ~go | in;
         go &= in;
-        val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
+        val = sample_coop<INTERP, QUANT, CNT, true>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked, trips);
         const float n_c = val.w + 1;
         const f3 C = delta_t * mk3(n_c * val.x, n_c * val.y, n_c * val.z);
         if (INTERP == 1) prev.set(f4{val.x, val.y, val.z, n_c - 1});
@@ -1032,7 +1101,7 @@ __device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &r
             go = alive & access;
             spin = alive & ~access;
         }
-        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked);
+        f4 val = sample_coop<INTERP, QUANT, CNT>(v, tex, blk, go, lookup, prev, u.data_min, mc, parked, trips);
         if (INTERP == 2) {                                      // .h:916-923
             const unsigned long long low = go & ballot(val.w < u.data_min);
             spin |= low;
