@@ -269,7 +269,8 @@ int photon_scene_set_element_train(photon_scene_t *scene, int mode);
 
 /* The partition of a march launch over its work queues (host restatement of the kernel's own functions, for tests).
  * photon_march_queue_count() queues -- 8 XCDs x (count / 8) sub-queues, 32 in the shipped build; consecutive groups form
- * CHUNKS of photon_march_queue_chunk(interpolation) groups (16 for the tricubic kernels, 128 for the trilinear ones), and
+ * CHUNKS of groups (photon_march_queue_chunk(interpolation): 16 for the tricubic kernels in source-major launches through
+ * volumes of up to 256^3 texels, 128 for the trilinear kernels -- and for every lens-major launch or larger volume), and
  * queue (xcd, sub) owns the chunks c with c % count == sub * 8 + xcd.  photon_march_queue_group: index of the k-th 64-ray
  * group that queue hands out (grows with k); photon_march_queue_size: how many of a launch's n_groups groups it owns.
  * Every group of a launch belongs to exactly one queue.  An xcd >= 8, a sub >= count / 8 or a groups_per_chunk that is

@@ -552,9 +552,12 @@ constexpr unsigned kQueues = 64;                                // room for 8 XC
 // Consecutive 64-ray groups an XCD's queue owns as one CHUNK: 2^shift.  Large chunks keep the rays of neighbouring sources
 // in one L2; small ones balance the XCDs' queues at the end of a launch.  Measured on C3 with the segmented march (HBM
 // traffic does not care: 4.0-4.15 GB): tricubic RK4 march with chunks of 128 / 32 / 16 / 8 groups 57.70 / 57.59 / 57.53 /
-// 57.55 ms (one GPU's eighth 7.60 / 7.55 / 7.53 / 7.51), trilinear RK4 19.83 / 19.89 / 19.92: 16 for the tricubic kernels,
-// 128 for the trilinear ones (launch_march).
-constexpr unsigned kChunkShiftCubic = 4, kChunkShiftLinear = 7;
+// 57.55 ms (one GPU's eighth 7.60 / 7.55 / 7.53 / 7.51), trilinear RK4 19.83 / 19.89 / 19.92: 16 for the tricubic kernels in
+// source-major launches through volumes of up to 256^3 texels, 128 otherwise (launch_march says why).
+#ifndef PHOTON_CHUNK_SHIFT_CUBIC
+#define PHOTON_CHUNK_SHIFT_CUBIC 4
+#endif
+constexpr unsigned kChunkShiftCubic = PHOTON_CHUNK_SHIFT_CUBIC, kChunkShiftLinear = 7;
 // The k-th group handed out by sub-queue `sub` of XCD `xcd`, C = 2^shift groups per chunk: chunk ((k / C) * 4 + sub) * 8 + xcd, group k % C of it.  Grows
 // with k, so the first k whose group lies past the launch ends the queue; every group belongs to exactly one (xcd, sub).
 __host__ __device__ inline unsigned march_queue_group(unsigned k, unsigned xcd, unsigned sub, unsigned shift) {
@@ -582,6 +585,7 @@ struct MarchArgs {
                                         // one runs until every ray has left): equal, halving or tapered pieces (plan_segments)
     unsigned epoch;                     // tag of this launch in RayStateDev::seg_flag
     unsigned *error;                    // waves that gave a segment up (zero unless the hand-off between segments is broken)
+    unsigned chunk_shift;               // log2 of the groups per queue chunk (launch_march)
 };
 typedef const __attribute__((address_space(4))) MarchArgs *MarchArgsPtr;
 template <class T>
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, (march_waves<INTERP, NOISE>()))
             if (lane == 0) k = atomicAdd(&march_args()->queue[(sub * 8u + x) * kQueueStride], 1u);
             k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             const unsigned n_rays = march_args()->n_rays;
-            const unsigned shift = INTERP == 2 ? kChunkShiftCubic : kChunkShiftLinear;
+            const unsigned shift = march_args()->chunk_shift;
             const unsigned gq = march_queue_size((n_rays + 63u) / 64u, x, sub, shift);
             const unsigned n_seg = SEG ? march_args()->segments : 1u;
             if (k >= gq * n_seg) break;                         // this queue is served (k < 2^26 / 64 * 255: no overflow)
@@ -2124,6 +2128,12 @@ static int launch_march(photon_scene *s, const photon_volume *vol, int algorithm
     margs.vol = vol->dev; margs.tex = tex; margs.n_rays = n; margs.st = s->ws; margs.counters = s->d_counters; margs.noise = s->dev.noise;
     margs.ray_base = ray_base; margs.idump = idump; margs.queue = s->d_queue; margs.profile = profile; margs.segments = segments;
     margs.epoch = s->march_epoch; margs.error = s->d_error;
+    // queue chunks: small ones (tail balance) for the tricubic kernels where neighbouring groups are neighbouring SOURCES and
+    // the volume is small enough for every L2 to hold what its waves touch; lens-major launches (neighbouring groups share
+    // a lens tile, their rays fan out over the whole volume) and large volumes keep the L2-friendly 128 -- C5 at a
+    // quarter: 11.0 GB of HBM traffic per launch with 16-group chunks against 3.8 GB with 128, 38.03 against 37.94 ms
+    margs.chunk_shift = interp == 2 && s->dev.ray_order == 0 && (size_t)vol->dev.nx * vol->dev.ny * vol->dev.nz <= ((size_t)1 << 24)
+                            ? kChunkShiftCubic : kChunkShiftLinear;
 #define PH_MARCH(A, I, S, N) do { if (!S && !N && segments > 1) hipLaunchKernelGGL((march_kernel<A, I, false, false, true>), mgrid, mblock, 0, stream, margs); \
                               else hipLaunchKernelGGL((march_kernel<A, I, S, N, false>), mgrid, mblock, 0, stream, margs); } while (0)
     if (algorithm == 3) hipLaunchKernelGGL((march_extra_kernel<3>), grid, block, 0, stream, vol->dev, n, s->ws, s->d_counters);
