@@ -83,9 +83,10 @@ __device__ __forceinline__ void path_stat(int, unsigned long long = 1) {}
 #endif
 constexpr int kBrickPitch = PHOTON_BRICK_PITCH;                  // texels between consecutive rows of the brick
 constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels between consecutive z-slabs
-// per wave: the tile (64 texels reserved; trilinear uses 8) + the brick: 8x8x4 texels for the tricubic sampler, 8x8x2 for
-// the trilinear one -- 7 KiB against 4 KiB, i.e. at most 5 against 10 workgroups of four waves in a CU's 160 KiB
-// -- and, for the trilinear kernels, one more 16-byte slot per lane behind the brick: the last value the lane sampled (PrevStash)
+// per wave: the tile(s) -- 4x4x7 = 112 texels for the tricubic sampler, two of 2x2x16 = 128 for the trilinear one -- + the
+// brick: 8x8x4 texels (tricubic), 8x8x2 (trilinear), rows padded -- 7.75 KiB against 5 KiB, i.e. at most 5 against 8
+// workgroups of four waves in a CU's 160 KiB -- and, with PHOTON_PREV_STASH, one more 16-byte slot per lane behind the
+// trilinear brick: the last value the lane sampled
 // Layers of the tricubic sampler's coherent tile: 4 (one cell: rounds 1-3) ... 8 (five cells of the column the wave travels
 // along).  C3, same box, march ms twice each: 4 layers 58.40 / 58.45, 6: 58.17 / 58.39, 7: 58.10 / 58.12, 8: 58.79 / 58.84 --
 // 8 KiB of LDS per wave, four waves per SIMD instead of five (and only 0.7 % slower for it: the kernel is not latency-bound).
