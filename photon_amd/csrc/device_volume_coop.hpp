@@ -67,9 +67,6 @@ __device__ __forceinline__ void path_stat(int, unsigned long long = 1) {}
 #ifndef PHOTON_TILE_RETRY_MASK
 #define PHOTON_TILE_RETRY_MASK 15  // an incoherent wave tries its tiles again on the trips of the march loop whose number & mask == 0
 #endif
-#ifndef PHOTON_REPAIR_INLINE
-#define PHOTON_REPAIR_INLINE 0
-#endif
 #ifndef PHOTON_TILE_LANE_PIN
 #define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch in the RK4 kernels (1) or left to the compiler (0)
 #endif
@@ -922,13 +919,6 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
             const float ambient = 1.000277;
             const f4 val_prev = prev.get();                     // the lane's last sampled value (parked in LDS)
             const unsigned long long repair = low & ballot(val_prev.w == 0);
-#if PHOTON_REPAIR_INLINE
-            if (repair != 0) {
-                const f4 t = tex3d_linear_coop<QUANT, PIN>(v, tex, blk, repair, lookup.x, lookup.y, lookup.z - 1, parked);
-                count_samples(mc, repair);
-                if (lane_of(repair)) val = f4{t.x, t.y, t.z, ambient - 1};
-            }
-#else
             if (repair != 0) {                                  // per lane, out of line: the same blend (the cooperative sampler's
                 count_samples(mc, repair);                      // own fallback), not a fourth copy of that sampler in the loop
                 if (lane_of(repair)) {
@@ -936,7 +926,6 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
                     val = f4{t.x, t.y, t.z, ambient - 1};
                 }
             }
-#endif
             if (lane_of(low & ~repair)) val = val_prev;
         }
     }
