@@ -2054,12 +2054,16 @@ static unsigned plan_segments(unsigned groups, unsigned slots, unsigned depth, i
     };
     unsigned S = cap;
     if (!forced) {
+        // Per sampler (refitted for the trilinear kernels after the sampler work of round 4: same sweep, full job 1 / 2 / 3 / 4
+        // pieces 17.22 / 17.33 / 17.39 / 17.48 ms, one GPU's eighth 1 / 3 / 4 / 6 / 8 / 12 pieces 2.359 / 2.276 / 2.288 / 2.298 /
+        // 2.315 / 2.376: a hand-off costs them 4.2 us -- they carry the last sampled value along -- and their launches drain
+        // over 0.31 of a last piece, in 0.72 us per unit: the full job runs whole, the eighth in 3 pieces).
         const double units = (double)depth * (algorithm == 2 ? 3.0 : 1.0) * (interp == 2 ? 3.0 : 1.0);
-        const double L = 0.82 * units, c = 2.9;
-        double best_cost = 0.75 * L;
+        const double L = (interp == 2 ? 0.82 : 0.72) * units, c = interp == 2 ? 2.9 : 4.2, drain = interp == 2 ? 0.75 : 0.31;
+        double best_cost = drain * L;
         S = 1;
         for (unsigned k = 2; k <= cap; k++) {
-            const double cost = fills * (k - 1) * c + 0.75 * L * lengths(k).back();
+            const double cost = fills * (k - 1) * c + drain * L * lengths(k).back();
             if (cost < best_cost) { best_cost = cost; S = k; }
         }
     }
