@@ -513,12 +513,22 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #define PHOTON_MARCH_WAVES 5
 #endif
 #ifndef PHOTON_MARCH_WAVES_LINEAR
-#define PHOTON_MARCH_WAVES_LINEAR 5     // a sixth wave (80 VGPRs) costs 20 spilled dwords in the RK4 loop: 27.7 vs 26.6 ms on C3 (r02)
-#endif
+#define PHOTON_MARCH_WAVES_LINEAR 6     // RK4 trilinear: a sixth wave (80 VGPRs) costs 18 spilled dwords in the loop (36 in the segmented instantiation) and
+#endif                                  // still wins since the sampler work of round 4 made the kernel wait-bound -- C3 17.19 -> 16.32 ms, C5 quarter 13.26 ->
+                                        // 12.49, one GPU's eighth of C3 2.278 -> 2.270 (round 2, 197 instructions per sample: 26.6 -> 27.7 ms)
+#ifndef PHOTON_MARCH_WAVES_EULER_LINEAR
+#define PHOTON_MARCH_WAVES_EULER_LINEAR 5   // Euler trilinear: the whole-march kernel needs 77 VGPRs and runs six waves per SIMD as it is; the segmented
+#endif                                      // one (89) would spill 17 for them: one GPU's eighth 0.845 -> 0.855 ms
 #ifndef PHOTON_MARCH_WAVES_NOISE
 #define PHOTON_MARCH_WAVES_NOISE 3      // the gradient-noise instantiations (Philox + Box-Muller in f64 inside the loop) need ~130 VGPRs: at five
 #endif                                  // waves per SIMD they spilled 46-70 of them into the loop (176-208 B of scratch per lane); three waves, no spill
-template <int INTERP, bool NOISE> constexpr int march_waves() { return NOISE ? PHOTON_MARCH_WAVES_NOISE : (INTERP == 1 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES); }
+template <int ALGO, int INTERP, bool NOISE> constexpr int march_waves() {
+    return NOISE ? PHOTON_MARCH_WAVES_NOISE : INTERP == 1 ? (ALGO == 2 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES_EULER_LINEAR) : PHOTON_MARCH_WAVES;
+}
+// resident march waves per SIMD of a launch (the segment planner's chip fill)
+static unsigned march_waves_of(int algorithm, int interp) {
+    return interp == 1 ? (algorithm == 2 ? PHOTON_MARCH_WAVES_LINEAR : 6 /* 77 VGPRs */) : PHOTON_MARCH_WAVES;
+}
 // Shader-clock stamp of a wave: s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
 // (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The chip lowers its clock under load, by an amount that differs from
 // device to device; the ratio of the two deltas, summed over the waves of a launch, is the clock the march actually ran
@@ -775,7 +785,7 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
 }
 
 template <int ALGO, int INTERP, bool SAVE, bool NOISE, bool SEG>
-__global__ __launch_bounds__(PHOTON_MARCH_BLOCK, (march_waves<INTERP, NOISE>())) void march_kernel(MarchArgs) {
+__global__ __launch_bounds__(PHOTON_MARCH_BLOCK, (march_waves<ALGO, INTERP, NOISE>())) void march_kernel(MarchArgs) {
     __shared__ f4 tiles[PHOTON_MARCH_BLOCK / 64][wave_lds_texels<INTERP>()];           // per wave: tile + brick, rows padded (device_volume_coop.hpp)
     f4 *const tile = tiles[threadIdx.x >> 6];
     const unsigned lane = threadIdx.x & 63u;
@@ -2089,7 +2099,7 @@ static unsigned plan_segments(unsigned groups, unsigned slots, unsigned depth, i
 // (host restatement for tests and documentation; PHOTON_MARCH_SEGMENT_SHAPE is honoured, PHOTON_MARCH_SEGMENTS is not).
 extern "C" int photon_march_segments_plan(unsigned n_rays, int depth, int ray_tracing_algorithm, int interpolation, int num_cus, int *halving) {
     if (depth < 1 || num_cus < 1 || (ray_tracing_algorithm != 1 && ray_tracing_algorithm != 2)) return 0;
-    const unsigned groups = (n_rays + 63u) / 64u, slots = (unsigned)num_cus * 4u * PHOTON_MARCH_WAVES;
+    const unsigned groups = (n_rays + 63u) / 64u, slots = (unsigned)num_cus * 4u * march_waves_of(ray_tracing_algorithm, interpolation);
     int shape = 0;
     unsigned s = 1, begin[kMaxSegments + 1];
     if (PHOTON_MARCH_PERSISTENT && groups >= slots + slots / 4) s = plan_segments(groups, slots, (unsigned)depth, ray_tracing_algorithm, interpolation, PHOTON_MARCH_SEGMENTS, false, begin, &shape);
@@ -2119,8 +2129,8 @@ static int launch_march(photon_scene *s, const photon_volume *vol, int algorithm
     MarchArgs margs{};
     if (PHOTON_MARCH_PERSISTENT && (algorithm == 1 || algorithm == 2) && !save && !s->dev.noise.add_ngrad) {
         const unsigned groups = (n + 63u) / 64u;
-        // resident march waves: five per SIMD (the launch bound of the march kernels)
-        const unsigned slots = (unsigned)s->num_cus * 4u * PHOTON_MARCH_WAVES;
+        // resident march waves: five or six per SIMD (the launch bounds of the march kernels)
+        const unsigned slots = (unsigned)s->num_cus * 4u * march_waves_of(algorithm, interp);
         bool forced = s->march_segments > 1;                // an explicit count segments launches of any size (tests)
         const int want = s->march_segments >= 0 ? s->march_segments : march_segments_default(&forced);
         if (want > 1 && (forced || groups >= slots + slots / 4)) {
