@@ -567,15 +567,35 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     return acc;
 }
 
-// The trilinear blend with per-lane, clamped addressing (incoherent waves).  Not inlined, for the same
-// reason as cubic_gather_fn: it is the rare path and would otherwise sit, with its eight address
-// computations, at every sampler call site of the march.
+// The trilinear blend with per-lane, clamped addressing (stragglers of an incoherent wave, the rare repair sample).  Not
+// inlined, for the same reason as cubic_gather_fn: it is the rare path and would otherwise sit, with its eight address
+// computations, at every sampler call site of the march.  And LEAN on purpose: under the AMDGPU calling convention what
+// the caller keeps live across the call sits ABOVE the callee's registers, so this function's VGPR count is part of the
+// march kernels' budget at every call site -- with all eight texels in flight it needed 52, which left the RK4 kernel (80
+// VGPRs, six waves per SIMD) 28 for its ray state and made it spill into its loop.  One x-pair of texels at a time (the
+// empty asm statements keep the compiler from hoisting the later loads): same lerp tree, same bits.
 __device__ __attribute__((noinline)) f4 linear_gather_fn(const f4 *__restrict__ tex, int nx, int ny, int nz, float x,
                                                          float y, float z, float weight_scale, float weight_inv) {
     const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
-    return linear_taps<true>(tex, nx, ny, nz, (int)fi, (int)fj, (int)fk, quant_weight(xb - fi, weight_scale, weight_inv),
-                             quant_weight(yb - fj, weight_scale, weight_inv), quant_weight(zb - fk, weight_scale, weight_inv));
+    const float a = quant_weight(xb - fi, weight_scale, weight_inv), b = quant_weight(yb - fj, weight_scale, weight_inv),
+                c = quant_weight(zb - fk, weight_scale, weight_inv);
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    const int i0 = clampi(i, 0, nx - 1), i1 = clampi(i + 1, 0, nx - 1);
+    const int j0 = clampi(j, 0, ny - 1), j1 = clampi(j + 1, 0, ny - 1);
+    const int k0 = clampi(k, 0, nz - 1), k1 = clampi(k + 1, 0, nz - 1);
+    auto row = [&](int kk, int jj) {                            // first-level lerp of one x-pair
+        const f4 *r = tex + (unsigned)((kk * ny + jj) * nx);    // < 2^31 texels (checked on the host)
+        f4 v = lerp4(ldtexel(r + i0), ldtexel(r + i1), a);
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        return v;
+    };
+    const f4 c00 = row(k0, j0), c10 = row(k0, j1);
+    f4 c0 = lerp4(c00, c10, b);
+    asm volatile("" : "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(c0.w));
+    const f4 c01 = row(k1, j0), c11 = row(k1, j1);
+    const f4 c1 = lerp4(c01, c11, b);
+    return lerp4(c0, c1, c);
 }
 
 // Inline asm on purpose: the builtin is folded away when the compiler can prove its operand uniform,
