@@ -503,7 +503,8 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 
 // Stage 1b: march the rays through the volume, in place on the SoA state (world frame).  One lane per ray;
 // the launch's ray order (source-major / lens-major, SceneDev::ray_order) decides which rays share a wave.
-// Launch bound: 5 waves per SIMD (<= 96 VGPRs).  A wave issues at most one VALU instruction per ~4 cycles, the
+// Launch bound: 5 waves per SIMD for the tricubic kernels (<= 96 VGPRs; their 7.75 KiB of LDS per wave allow no more), 6
+// for the RK4 trilinear ones (below).  A wave issues at most one VALU instruction per ~4 cycles, the
 // SIMD one per 2, and every wave spends part of its time waiting on LDS: the more resident waves the better
 // (C3 tricubic: 3 waves 100.8 ms, 4 waves 93.2 ms at the time; now 4 waves 68.8, 5 waves 67.1 ms; trilinear 28.0
 // -> 25.1 ms).  What made 96 registers reachable was the out-of-line gather fallback: under the AMDGPU calling
@@ -513,12 +514,13 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #define PHOTON_MARCH_WAVES 5
 #endif
 #ifndef PHOTON_MARCH_WAVES_LINEAR
-#define PHOTON_MARCH_WAVES_LINEAR 6     // RK4 trilinear: a sixth wave (80 VGPRs) costs 18 spilled dwords in the loop (36 in the segmented instantiation) and
-#endif                                  // still wins since the sampler work of round 4 made the kernel wait-bound -- C3 17.19 -> 16.32 ms, C5 quarter 13.26 ->
-                                        // 12.49, one GPU's eighth of C3 2.278 -> 2.270 (round 2, 197 instructions per sample: 26.6 -> 27.7 ms)
+#define PHOTON_MARCH_WAVES_LINEAR 6     // RK4 trilinear: a sixth wave (80 VGPRs) cost 18 spilled dwords in the loop (36 in the segmented instantiation) and
+#endif                                  // still won once the sampler work of round 4 had left the kernel waiting -- C3 17.19 -> 16.32 ms, C5 quarter 13.26 ->
+                                        // 12.49, one GPU's eighth of C3 2.278 -> 2.270 (round 2, 197 instructions per sample: 26.6 -> 27.7 ms); with the
+                                        // lean out-of-line gather (device_volume_coop.hpp) 3 / 26 spilled dwords: 16.29 and 2.21 ms.  Seven waves: 16.75
 #ifndef PHOTON_MARCH_WAVES_EULER_LINEAR
-#define PHOTON_MARCH_WAVES_EULER_LINEAR 5   // Euler trilinear: the whole-march kernel needs 77 VGPRs and runs six waves per SIMD as it is; the segmented
-#endif                                      // one (89) would spill 17 for them: one GPU's eighth 0.845 -> 0.855 ms
+#define PHOTON_MARCH_WAVES_EULER_LINEAR 5   // Euler trilinear: the whole-march kernel needs 71 VGPRs and runs seven waves per SIMD as it is; the segmented
+#endif                                      // one (83) would spill for a sixth: one GPU's eighth 0.845 -> 0.855 ms
 #ifndef PHOTON_MARCH_WAVES_NOISE
 #define PHOTON_MARCH_WAVES_NOISE 3      // the gradient-noise instantiations (Philox + Box-Muller in f64 inside the loop) need ~130 VGPRs: at five
 #endif                                  // waves per SIMD they spilled 46-70 of them into the loop (176-208 B of scratch per lane); three waves, no spill
@@ -527,7 +529,7 @@ template <int ALGO, int INTERP, bool NOISE> constexpr int march_waves() {
 }
 // resident march waves per SIMD of a launch (the segment planner's chip fill)
 static unsigned march_waves_of(int algorithm, int interp) {
-    return interp == 1 ? (algorithm == 2 ? PHOTON_MARCH_WAVES_LINEAR : 6 /* 77 VGPRs */) : PHOTON_MARCH_WAVES;
+    return interp == 1 ? (algorithm == 2 ? PHOTON_MARCH_WAVES_LINEAR : 6 /* whole marches: 71 VGPRs */) : PHOTON_MARCH_WAVES;
 }
 // Shader-clock stamp of a wave: s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
 // (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The chip lowers its clock under load, by an amount that differs from
