@@ -519,8 +519,9 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
                                         // 12.49, one GPU's eighth of C3 2.278 -> 2.270 (round 2, 197 instructions per sample: 26.6 -> 27.7 ms); with the
                                         // lean out-of-line gather (device_volume_coop.hpp) 3 / 26 spilled dwords: 16.29 and 2.21 ms.  Seven waves: 16.75
 #ifndef PHOTON_MARCH_WAVES_EULER_LINEAR
-#define PHOTON_MARCH_WAVES_EULER_LINEAR 5   // Euler trilinear: the whole-march kernel needs 71 VGPRs and runs seven waves per SIMD as it is; the segmented
-#endif                                      // one (83) would spill for a sixth: one GPU's eighth 0.845 -> 0.855 ms
+#define PHOTON_MARCH_WAVES_EULER_LINEAR 6   // Euler trilinear: the whole-march kernel needs 71 VGPRs (seven waves per SIMD as it is); the segmented one 83:
+#endif                                      // capped at 80 it spills 2 dwords and runs a sixth wave -- one GPU's eighth 0.849 -> 0.809 ms, a quarter 1.625 ->
+                                            // 1.531 (before the lean out-of-line gather the cap cost 17 spilled dwords: 0.845 -> 0.855)
 #ifndef PHOTON_MARCH_WAVES_NOISE
 #define PHOTON_MARCH_WAVES_NOISE 3      // the gradient-noise instantiations (Philox + Box-Muller in f64 inside the loop) need ~130 VGPRs: at five
 #endif                                  // waves per SIMD they spilled 46-70 of them into the loop (176-208 B of scratch per lane); three waves, no spill
