@@ -18,9 +18,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libparallel_ray_tracing.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 
-SOURCES = [os.path.join(CSRC, "photon_core.hip"), os.path.join(CSRC, "photon_sort.hip")]
+UNITS = ("photon_pool", "photon_volume", "photon_scene", "photon_march", "photon_march_linear", "photon_march_cubic", "photon_march_extra",
+         "photon_sensor", "photon_trace", "photon_post", "photon_abi", "photon_sort", "photon_version")
+SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 HEADERS = [os.path.join(CSRC, h) for h in ("device_vec.hpp", "device_volume.hpp", "device_volume_coop.hpp", "device_volume_extra.hpp", "device_optics.hpp",
-                                            "photon_sort.hpp")] + [
+                                            "march_args.hpp", "march_kernel.hpp", "photon_internal.hpp", "photon_pool.hpp", "photon_sort.hpp")] + [
     os.path.join(ROOT, "include", "parallel_ray_tracing.h"),
     os.path.join(ROOT, "include", "photon_det_math.h"),
     os.path.join(ROOT, "include", "photon_philox.h"),
@@ -73,18 +75,54 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + [os.path.abspath(__file__)])
 
 
-def _compile(src: str, extra_flags, verbose: bool, out_dir: str) -> str:
+def build_id(extra_flags=()) -> str:
+    """What photon_version() reports after the library's name: the commit the tree was built from (with -dirty when the
+    library's sources differ from it; 'nogit' on a box without the history) and the non-default -DPHOTON_* switches."""
+    try:
+        sha = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "photon_amd/csrc", "include", "photon_amd/build.py"], cwd=ROOT,
+                               capture_output=True, text=True, check=True).stdout.strip()
+        sha += "-dirty" if dirty else ""
+    except Exception:       # noqa: BLE001
+        sha = "nogit"
+    switches = sorted(f for f in extra_flags if f.startswith("-DPHOTON_"))
+    return sha + " " + ("default" if not switches else "variant[" + " ".join(f[2:] for f in switches) + "]")
+
+
+def _stale(src: str, obj: str, key: str) -> bool:
+    """An object is reused when it is newer than its source, every header and this script, and was compiled with the same
+    command line (recorded next to it)."""
+    stamp = obj + ".cmd"
+    if not (os.path.exists(obj) and os.path.exists(stamp)):
+        return True
+    t = os.path.getmtime(obj)
+    if any(os.path.getmtime(p) > t for p in [src] + HEADERS + [os.path.abspath(__file__)]):
+        return True
+    with open(stamp) as f:
+        return f.read() != key
+
+
+def _compile(src: str, extra_flags, verbose: bool, out_dir: str, force: bool) -> str:
     obj = os.path.join(out_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
-    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+    flags = list(HIPCC_FLAGS) + list(extra_flags)
+    if os.path.basename(src) == "photon_version.hip":
+        flags.append('-DPHOTON_BUILD_ID="%s"' % build_id(extra_flags))
+    cmd = [hipcc_path()] + flags + ["-c", src, "-o", obj]
+    key = " ".join(cmd)
+    if not force and not _stale(src, obj, key):
+        return obj
     if verbose:
-        print(" ".join(cmd), file=sys.stderr, flush=True)
+        print(key, file=sys.stderr, flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC, stdout=sys.stderr)
+    with open(obj + ".cmd", "w") as f:
+        f.write(key)
     return obj
 
 
 def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out_path: str = None) -> str:
-    """Compile every translation unit (in parallel) and link the shared library.  Concurrent callers (ranks of one
-    node, pytest workers) serialise on a lock file; whoever comes second finds the library fresh."""
+    """Compile the stale translation units (in parallel) and link the shared library.  Concurrent callers (ranks of one
+    node, pytest workers) serialise on a lock file; whoever comes second finds the library fresh.  force=True recompiles
+    every unit."""
     import fcntl
     from concurrent.futures import ThreadPoolExecutor
     target = out_path or LIB_PATH
@@ -96,8 +134,8 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out
         fcntl.flock(lock, fcntl.LOCK_EX)
         if out_path is None and not force and not needs_build():
             return LIB_PATH
-        with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
-            objs = list(pool.map(lambda src: _compile(src, extra_flags, verbose, obj_dir), SOURCES))
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), max(1, len(os.sched_getaffinity(0))))) as pool:
+            objs = list(pool.map(lambda src: _compile(src, extra_flags, verbose, obj_dir, force), SOURCES))
         tmp = target + f".tmp{os.getpid()}"
         cmd = [hipcc_path()] + link_flags() + ["-o", tmp] + objs
         if verbose:

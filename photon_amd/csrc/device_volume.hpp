@@ -22,8 +22,6 @@ struct VolumeDev {
     int interpolation;          // 1 trilinear, 2 tricubic
     float weight_scale;         // trilinear weights: 0 = exact f32, 256 = NVIDIA texture-unit emulation (8 fractional bits)
     float weight_inv;           // 1 / weight_scale (a power of two: exact), 0 when weight_scale is 0
-    int weight_fast;            // the grid is small enough for the one-instruction-shorter form of the fixed-point weights
-                                // (tex3d_linear_coop: largest n x weight_scale <= 2^21)
     const f4 *texels;           // grad n (xyz), n-1 (w)   [nz][ny][nx]
     const f4 *coeffs;           // B-spline coefficients    [nz][ny][nx] (interpolation == 2)
 };
@@ -174,6 +172,19 @@ __device__ __forceinline__ bool inside_box(f3 p, const VolumeDev &v, f3 l) {    
 }
 __device__ __forceinline__ bool can_access(const VolumeDev &v, f3 l) {                  // .h:253-277
     return !(l.x < 0 || l.y < 0 || l.z < 0 || l.x >= v.nx || l.y >= v.ny || l.z >= v.nz);
+}
+
+// Intermediate ray dumps (save_intermediate_ray_data): position / direction at the start of each
+// of the first `slots` iterations, [ray][slot] float3, world frame.  Like the reference only the
+// trilinear branches record them (.h:784-790, 1004-1008); unlike it the ray index is bounds-checked
+// (the reference indexes a num_lightrays_save-sized buffer with the unchecked thread id).
+struct InterDump { float *pos, *dir; int slots, num_save; unsigned ray; };
+__device__ __forceinline__ void record_intermediate(const InterDump &d, int loop_ctr, f3 p, f3 q) {
+    if (d.pos != nullptr && loop_ctr < d.slots && d.ray < (unsigned)d.num_save) {
+        const size_t o = ((size_t)d.ray * d.slots + loop_ctr) * 3;
+        d.pos[o] = p.x; d.pos[o + 1] = p.y; d.pos[o + 2] = p.z;
+        d.dir[o] = q.x; d.dir[o + 1] = q.y; d.dir[o + 2] = q.z;
+    }
 }
 
 constexpr int kLoopMax = 10000000;      // loop_ctr_max (.h:765,981)

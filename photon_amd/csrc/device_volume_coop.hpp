@@ -44,31 +44,14 @@ __device__ __forceinline__ void path_stat(int, unsigned long long = 1) {}
 #ifndef PHOTON_BRICK_PASSES
 #define PHOTON_BRICK_PASSES 6       // bricks parked per sample before the remaining lanes fall back to the per-lane gather
 #endif
-#ifndef PHOTON_TILE_REUSE
-#define PHOTON_TILE_REUSE 1
-#endif
-// Two register-pressure measures for the trilinear kernels, measured in round 4 on C3 (same box, Mrays/s; round 3's library
-// 465-467 RK4 / 1101 Euler): val_prev in a per-lane LDS slot -- RK4 461 with, 463-468 without; Euler 1072 / 1079: OFF;
-// the tile's lane offsets recomputed per fetch instead of hoisted (and spilled) -- RK4 468 with, 453 without; Euler 1079
-// with, 1095 without (a fetch every other sample weighs more where a sample is a third of the work): ON for RK4 only.
-#ifndef PHOTON_PREV_STASH
-#define PHOTON_PREV_STASH 0         // the trilinear branches' val_prev in a per-lane LDS slot (1) or in four VGPRs (0)
-#endif
-#ifndef PHOTON_WEIGHT_FAST
-#define PHOTON_WEIGHT_FAST 0        // a one-instruction-shorter exact form of the fixed-point trilinear weights where the grid allows it
-#endif                              // (tex3d_linear_coop): bit-identical, and SLOWER -- RK4 469 -> 459, Euler 1092 -> 1080 Mrays/s on C3: the
-                                    // wave-uniform branch costs these register-bound kernels more than three instructions save.  Off.
 #ifndef PHOTON_LINEAR_TILE_LAYERS
-#define PHOTON_LINEAR_TILE_LAYERS 16        // layers of the trilinear sampler's coherent tile: 4 / 8 / 16 (3 / 7 / 15 cells of a column) or 2 (one cell: rounds 1-3)
+#define PHOTON_LINEAR_TILE_LAYERS 16        // layers of a trilinear sampler's coherent tile: 4 / 8 / 16 (3 / 7 / 15 cells of a column)
 #endif
 #ifndef PHOTON_LINEAR_TILES
 #define PHOTON_LINEAR_TILES 2       // tiles the trilinear sampler parks per wave: 2 = a wave across two columns (two light sources) is served like a coherent one
 #endif
 #ifndef PHOTON_TILE_RETRY_MASK
 #define PHOTON_TILE_RETRY_MASK 15  // an incoherent wave tries its tiles again on the trips of the march loop whose number & mask == 0
-#endif
-#ifndef PHOTON_TILE_LANE_PIN
-#define PHOTON_TILE_LANE_PIN 1      // the trilinear tile's lane offsets recomputed per fetch in the RK4 kernels (1) or left to the compiler (0)
 #endif
 // Row pitch of the brick in LDS, in texels.  The brick is 8 texels wide; with a pitch of 8 the 16-byte reads of lanes
 // whose blocks sit two rows apart land on the same four banks (a ds_read_b128 serves 16 lanes per LDS cycle from 64
@@ -82,8 +65,7 @@ constexpr int kBrickPitch = PHOTON_BRICK_PITCH;                  // texels betwe
 constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels between consecutive z-slabs
 // per wave: the tile(s) -- 4x4x7 = 112 texels for the tricubic sampler, two of 2x2x16 = 128 for the trilinear one -- + the
 // brick: 8x8x4 texels (tricubic), 8x8x2 (trilinear), rows padded -- 7.75 KiB against 5 KiB, i.e. at most 5 against 8
-// workgroups of four waves in a CU's 160 KiB -- and, with PHOTON_PREV_STASH, one more 16-byte slot per lane behind the
-// trilinear brick: the last value the lane sampled
+// workgroups of four waves in a CU's 160 KiB
 // Layers of the tricubic sampler's coherent tile: 4 (one cell: rounds 1-3) ... 8 (five cells of the column the wave travels
 // along).  C3, same box, march ms twice each: 4 layers 58.40 / 58.45, 6: 58.17 / 58.39, 7: 58.10 / 58.12, 8: 58.79 / 58.84 --
 // 8 KiB of LDS per wave, four waves per SIMD instead of five (and only 0.7 % slower for it: the kernel is not latency-bound).
@@ -92,9 +74,8 @@ constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels betwee
 #endif
 constexpr int kCubicTileLayers = PHOTON_CUBIC_TILE_LAYERS;
 static_assert(kCubicTileLayers >= 4 && kCubicTileLayers <= 8, "PHOTON_CUBIC_TILE_LAYERS");
-template <int INTERP> constexpr int tile_texels() { return INTERP == 2 ? 16 * kCubicTileLayers : (PHOTON_LINEAR_TILE_LAYERS >= 4 && PHOTON_LINEAR_TILES * PHOTON_LINEAR_TILE_LAYERS * 4 > 64 ? PHOTON_LINEAR_TILES * PHOTON_LINEAR_TILE_LAYERS * 4 : 64); }
-template <int INTERP> constexpr int wave_lds_texels() { return tile_texels<INTERP>() + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 && PHOTON_PREV_STASH ? 64 : 0); }
-constexpr int kPrevStashOffset = tile_texels<1>() + 2 * kBrickSlab;           // texel slot of lane 0's stash in a trilinear wave's LDS area
+template <int INTERP> constexpr int tile_texels() { return INTERP == 2 ? 16 * kCubicTileLayers : PHOTON_LINEAR_TILES * PHOTON_LINEAR_TILE_LAYERS * 4; }
+template <int INTERP> constexpr int wave_lds_texels() { return tile_texels<INTERP>() + (INTERP == 2 ? 4 : 2) * kBrickSlab; }
 constexpr int kWaveLdsTexels = wave_lds_texels<2>();
 
 // 64-tap sum (slab order) over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
@@ -150,16 +131,7 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     return acc;
 }
 
-#ifndef PHOTON_DPP_SLAB
-#define PHOTON_DPP_SLAB 1
-#endif
-#ifndef PHOTON_DUAL_SLAB
-#define PHOTON_DUAL_SLAB 0          // experiment: z-slabs 1 and 2 of the hybrid chain interleaved (two accumulators)
-#endif
-#ifndef PHOTON_DPP_ROWS
-#define PHOTON_DPP_ROWS 4           // rows of z-slab 0 (four taps each) served from registers; the rest of the slab comes from LDS
-#endif
-// The coherent tile's 64-tap sum with z-slab 0 served from REGISTERS instead of LDS (PHOTON_DPP_SLAB=1): `reg` holds, in
+// The coherent tile's 64-tap sum with z-slab 0 served from REGISTERS instead of LDS: `reg` holds, in
 // every 16-lane row of the wave, the 16 texels of slab 0 (lane l: texel l & 15), and its 16 taps are v_fmac_f32_dpp with
 // row_newbcast:k -- every lane multiplies ITS weight with lane k's texel.  16 of the sample's 64 broadcast ds_read_b128
 // disappear; a DPP multiply-add costs more issue time than a plain one (round 2's micro-benchmark: ~1.35x), and the
@@ -239,30 +211,15 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     "v_fmac_f32_dpp %1, %9, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" \
     "v_fmac_f32_dpp %2, %10, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" \
     "v_fmac_f32_dpp %3, %11, %27 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-#if PHOTON_DPP_ROWS == 1
-#define PH_DPP_ROWS_TEXT PH_DPP_ROW0
-#elif PHOTON_DPP_ROWS == 2
-#define PH_DPP_ROWS_TEXT PH_DPP_ROW0 PH_DPP_ROW1
-#elif PHOTON_DPP_ROWS == 3
-#define PH_DPP_ROWS_TEXT PH_DPP_ROW0 PH_DPP_ROW1 PH_DPP_ROW2
-#else
 #define PH_DPP_ROWS_TEXT PH_DPP_ROW0 PH_DPP_ROW1 PH_DPP_ROW2 PH_DPP_ROW3
-#endif
-// the four texels the asm block reads ahead: row 0 of slab 1 -- or, with slabs 1 and 2 interleaved, their first two taps each
-#if PHOTON_DUAL_SLAB
-#define PH_DS_OFF1 "256"
-#define PH_DS_OFF2 "16"
-#define PH_DS_OFF3 "272"
-#else
+// the four texels the asm block reads ahead: row 0 of slab 1
 #define PH_DS_OFF1 "16"
 #define PH_DS_OFF2 "32"
 #define PH_DS_OFF3 "48"
-#endif
 __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const float (&wx)[4], const float (&wy)[4],
                                                 const float (&wz)[4]) {
     typedef float v4f __attribute__((ext_vector_type(4)));
-    constexpr int R = PHOTON_DPP_ROWS;                              // rows (of four taps) of z-slab 0 served from registers
-    static_assert(R >= 1 && R <= 4, "PHOTON_DPP_ROWS");
+    constexpr int R = 4;                                            // rows (of four taps) of z-slab 0 served from registers: all of it
     float wxy[4][4];
 #pragma unroll
     for (int b = 0; b < 4; b++)
@@ -286,46 +243,10 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
             : "memory");
     f4 t[4] = {f4{t0.x, t0.y, t0.z, t0.w}, f4{t1.x, t1.y, t1.z, t1.w}, f4{t2.x, t2.y, t2.z, t2.w}, f4{t3.x, t3.y, t3.z, t3.w}};
     f4 acc = f4{0, 0, 0, 0};
-    if (R == 4) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};     // slab 0 complete (else: at r == 3 below)
+    acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};                 // slab 0 complete
     float w0 = wxy[0][0];
-#if PHOTON_DUAL_SLAB
-    // EXPERIMENT (round 4, verdict item 7): z-slabs 1 and 2 interleaved tap by tap -- two accumulators, eight independent
-    // multiply-add chains in flight instead of four, each chain in its own order (same bits); slab 3 alone afterwards.  The
-    // texel ring stays four slots: slot j % 4 holds the texel of the j-th tap in ISSUE order -- j = 2 * (4 b + a) + (slab - 1)
-    // -- refilled three taps ahead; the asm block above read taps 0-3 (its offsets: PH_DS_OFF*), and the last four refills
-    // are row 0 of slab 3 for the loop below.
-    static_assert(R == 4, "PHOTON_DUAL_SLAB needs all of slab 0 from registers");
-    {
-        f4 s2 = f4{0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const int slab = 1 + (j & 1), bb = (j >> 1) >> 2, aa = (j >> 1) & 3;
-            const f4 ta = t[j & 3];
-            const float w = (aa == 0 && bb == 0) ? w0 : wxy[bb][aa];
-            if (slab == 1) {
-                if (aa == 0 && bb == 0) s = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
-                else s = f4{fmaf(w, ta.x, s.x), fmaf(w, ta.y, s.y), fmaf(w, ta.z, s.z), fmaf(w, ta.w, s.w)};
-                asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w) : : "memory");
-            } else {
-                if (aa == 0 && bb == 0) s2 = f4{w * ta.x, w * ta.y, w * ta.z, w * ta.w};
-                else s2 = f4{fmaf(w, ta.x, s2.x), fmaf(w, ta.y, s2.y), fmaf(w, ta.z, s2.z), fmaf(w, ta.w, s2.w)};
-                asm volatile("" : "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w) : : "memory");
-            }
-            const int n = j + 4;                                    // the tap this slot serves next
-            if (n < 32) t[j & 3] = ldtexel(blk + (1 + (n & 1)) * 16 + ((n >> 1) >> 2) * 4 + ((n >> 1) & 3));
-            else t[j & 3] = ldtexel(blk + 48 + (n - 32));           // slab 3, row 0
-            asm volatile("" : "+v"(w0) : : "memory");
-        }
-        acc = f4{fmaf(wz[1], s.x, acc.x), fmaf(wz[1], s.y, acc.y), fmaf(wz[1], s.z, acc.z), fmaf(wz[1], s.w, acc.w)};
-        acc = f4{fmaf(wz[2], s2.x, acc.x), fmaf(wz[2], s2.y, acc.y), fmaf(wz[2], s2.z, acc.z), fmaf(wz[2], s2.w, acc.w)};
-        asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
-    }
-#pragma unroll
-    for (int r = 12; r < 16; r++) {                                 // slab 3 from LDS, as in cubic_taps_lds
-#else
 #pragma unroll
     for (int r = R; r < 16; r++) {                                  // the rest of the tile from LDS, as in cubic_taps_lds
-#endif
         const int b = r & 3, c = r >> 2;
 #pragma unroll
         for (int a = 0; a < 4; a++) {
@@ -346,39 +267,6 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
     return acc;
 }
 
-#ifndef PHOTON_ABLATE_SGPR_CHAIN
-#define PHOTON_ABLATE_SGPR_CHAIN 0  // MEASUREMENT ONLY (wrong numbers): the coherent chain as 256 plain multiply-adds whose texel operand is an SGPR --
-#endif                              // no LDS read, no DPP form: the floor of a sampler that would bring its texels in through the scalar cache
-#if PHOTON_ABLATE_SGPR_CHAIN
-__device__ __forceinline__ f4 cubic_taps_ablate(const float (&wx)[4], const float (&wy)[4], const float (&wz)[4]) {
-    float wxy[4][4];
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-        for (int a = 0; a < 4; a++) wxy[b][a] = wx[a] * wy[b];
-    float tx, ty, tz, tw;                                       // every texel = (0, 0, 0, 0.01), opaque to the compiler, in SGPRs
-    asm volatile("s_mov_b32 %0, 0\n\ts_mov_b32 %1, 0\n\ts_mov_b32 %2, 0\n\ts_mov_b32 %3, 0x3c23d70a" : "=s"(tx), "=s"(ty), "=s"(tz), "=s"(tw));
-    f4 acc = f4{0, 0, 0, 0}, s = f4{0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int b = r & 3, c = r >> 2;
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const float w = wxy[b][a];
-            if (a == 0 && b == 0) s = f4{w * tx, w * ty, w * tz, w * tw};
-            else s = f4{fmaf(w, tx, s.x), fmaf(w, ty, s.y), fmaf(w, tz, s.z), fmaf(w, tw, s.w)};
-            asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w), "+s"(tx), "+s"(ty), "+s"(tz), "+s"(tw));
-        }
-        if (b == 3) {
-            if (c == 0) acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};
-            else acc = f4{fmaf(wz[c], s.x, acc.x), fmaf(wz[c], s.y, acc.y), fmaf(wz[c], s.z, acc.z), fmaf(wz[c], s.w, acc.w)};
-            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));
-        }
-    }
-    return acc;
-}
-#endif
-
 // Lane predicates of the march are kept as WAVE MASKS (64-bit, wave-uniform, SGPR pairs): a mask comes out of
 // ballot(one comparison) -- a single v_cmp writing an SGPR pair -- and masks combine with integer & | ~ on the scalar
 // unit.  A predicate that is an AND / OR of i1 values reaches ballot() as a 0/1 VGPR instead (v_cndmask + v_cmp per use),
@@ -393,7 +281,7 @@ __device__ __forceinline__ bool lane_of(unsigned long long mask) { return __buil
 // ti, tj, tk: the tricubic sampler's current CELL (the one the register slab belongs to), the trilinear sampler's column and
 // base layer (tile A; ui, uj, uk: tile B).  ci, cj, k0, coff (tricubic, tiles deeper than one cell): the tile's column (bit patterns), the k of its first
 // cell, and the current cell's texel offset in it.
-struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; int ci, cj, k0, coff; int ui, uj, uk; };      // reg: z-slab 0 of the current cell in registers (PHOTON_DPP_SLAB, per lane)
+struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; int ci, cj, k0, coff; int ui, uj, uk; };      // reg: z-slab 0 of the current cell in registers (per lane)
 __device__ __forceinline__ Parked parked_none() {                // 0x7fffffff: a NaN pattern no floor() of a sampled coordinate has
     return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}, 0x7fffffff, 0x7fffffff, 0, 0, 0x7fffffff, 0x7fffffff, 0x7fffffff};
 }
@@ -426,7 +314,6 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
     bspline_weights(zg - fk, wz[0], wz[1], wz[2], wz[3]);
     const int lane = threadIdx.x & 63;
     if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
-#if PHOTON_CUBIC_TILE_LAYERS > 4
     {
         // COHERENT wave -- every sampling lane in ONE cell (BOS: always, except where a wave straddles two sources or a
         // cone straddles a texel boundary).  The parked tile is 4 x 4 texels wide and TL layers deep: TL - 3 cells of the
@@ -470,7 +357,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                     dz = ck - k0;
                 }
                 parked.coff = dz * 16;
-                if (PHOTON_DPP_SLAB) parked.reg = ldtexel(blk + parked.coff + (lane & 15));   // slab 0 of the cell, into every 16-lane row
+                parked.reg = ldtexel(blk + parked.coff + (lane & 15));   // slab 0 of the cell, into every 16-lane row
                 parked.ti = c.i; parked.tj = c.j; parked.tk = c.k;
                 hit = true;
             }
@@ -478,47 +365,12 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         if (hit) {
             path_stat(0);
             const f4 *cell = blk + parked.coff;
-#if PHOTON_ABLATE_SGPR_CHAIN == 2                                // MEASUREMENT ONLY: no chain at all (the weights kept alive): what everything else costs
-            const float wsum = ((wx[0] + wx[1]) + (wx[2] + wx[3])) + ((wy[0] + wy[1]) + (wy[2] + wy[3])) + ((wz[0] + wz[1]) + (wz[2] + wz[3]));
-            const f4 acc = f4{0, 0, 0, fmaf(wsum, 0.0f, 0.01f)};
-#elif PHOTON_ABLATE_SGPR_CHAIN
-            const f4 acc = cubic_taps_ablate(wx, wy, wz);
-#else
-            const f4 acc = PHOTON_DPP_SLAB ? cubic_taps_hybrid(cell, parked.reg, wx, wy, wz) : cubic_taps_lds<4, 16>(cell, wx, wy, wz);
-#endif
+            const f4 acc = cubic_taps_hybrid(cell, parked.reg, wx, wy, wz);
             __builtin_amdgcn_wave_barrier();
             return acc;
         }
         parked.ti = 0x7fffffff;                                 // to the bricks: the cell is forgotten (the tile stays)
     }
-#else
-    {
-        // COHERENT wave -- every sampling lane wants the block of the first one (BOS: always, except where a
-        // wave straddles two sources or a cone straddles a texel boundary): one load instruction for the
-        // whole 4x4x4 block, lane l <-> texel (l&3, (l>>2)&3, l>>4), clamp-to-edge per texel, parked in the
-        // tile; then the chain with broadcast reads -- on every lane, unpredicated: a lane that does not sample reads
-        // the same (valid) tile and produces a value nobody uses.
-        const Lead c = lead_of(need, fi, fj, fk);
-        if ((same_block(c, fi, fj, fk) & need) == need) {       // wave-uniform
-            path_stat(0);
-            if (!PHOTON_TILE_REUSE || c.i != parked.ti || c.j != parked.tj || c.k != parked.tk) {     // wave-uniform (SALU compares)
-                path_stat(1);
-                const int ci = (int)__int_as_float(c.i), cj = (int)__int_as_float(c.j), ck = (int)__int_as_float(c.k);
-                const int tx = clampi(ci - 1 + (lane & 3), 0, v.nx - 1), ty = clampi(cj - 1 + ((lane >> 2) & 3), 0, v.ny - 1),
-                          tz = clampi(ck - 1 + (lane >> 4), 0, v.nz - 1);
-                const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));      // < 2^31 texels (checked on the host)
-                __builtin_amdgcn_wave_barrier();
-                *reinterpret_cast<float4 *>(blk + lane) = make_float4(t.x, t.y, t.z, t.w);
-                __builtin_amdgcn_wave_barrier();
-                if (PHOTON_DPP_SLAB) parked.reg = ldtexel(blk + (lane & 15));      // slab 0, once per block, into every 16-lane row
-                parked.ti = c.i; parked.tj = c.j; parked.tk = c.k;
-            }
-            const f4 acc = PHOTON_DPP_SLAB ? cubic_taps_hybrid(blk, parked.reg, wx, wy, wz) : cubic_taps_lds<4, 16>(blk, wx, wy, wz);
-            __builtin_amdgcn_wave_barrier();
-            return acc;
-        }
-    }
-#endif
     // INCOHERENT wave (full-aperture cones, source boundaries: the lanes' blocks form a patch a few texels wide
     // in one z-slab).  Serving it group by group would cost the whole wave one chain per distinct block.
     // Instead: park the 8x8x4 BRICK around the first unserved lane's block -- four loads per lane -- and let
@@ -538,7 +390,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         const bool in_brick = !done && bk == ck && (unsigned)di <= 4u && (unsigned)dj <= 4u;
         path_stat(3);
         path_stat(6, (unsigned long long)__popcll(ballot(in_brick)));
-        if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
+        if (ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform: the brick is not parked yet
             path_stat(4);
             __builtin_amdgcn_wave_barrier();
             int l = lane;
@@ -624,24 +476,13 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
     const float fi = floorf(xb), fj = floorf(yb), fk = floorf(zb);
     float a = xb - fi, b = yb - fj, c = zb - fk;
     if (QUANT) {                                                // texture-unit weights (8 fractional bits)
-        if (PHOTON_WEIGHT_FAST && v.weight_fast) {              // wave-uniform
-            // round(frac(xb) S) / S, ties up, from xb itself: K = floor(xb S + 1/2), weight = K / S - floor(xb).  With S = 2^bits,
-            // xb = fi + a exactly (a = xb - fi is exact) and xb S + 1/2 exact in f32 while xb S < 2^22 -- i.e. for every
-            // sampled coordinate of a grid with n S <= 2^21, what weight_fast says -- floor(xb S + 1/2) = fi S + floor(a S + 1/2);
-            // K / S - fi is a multiple of 1/S in [0, 1], so the fused multiply-add returns it exactly: the bits of the
-            // two-step form below (and of the CPU checker's), one instruction fewer per axis.
-            a = fmaf(floorf(fmaf(xb, v.weight_scale, 0.5f)), v.weight_inv, -fi);
-            b = fmaf(floorf(fmaf(yb, v.weight_scale, 0.5f)), v.weight_inv, -fj);
-            c = fmaf(floorf(fmaf(zb, v.weight_scale, 0.5f)), v.weight_inv, -fk);
-        } else {
-            a = floorf(fmaf(a, v.weight_scale, 0.5f)) * v.weight_inv;       // quant_weight() with the scale known positive
-            b = floorf(fmaf(b, v.weight_scale, 0.5f)) * v.weight_inv;
-            c = floorf(fmaf(c, v.weight_scale, 0.5f)) * v.weight_inv;
-        }
+        a = floorf(fmaf(a, v.weight_scale, 0.5f)) * v.weight_inv;           // quant_weight() with the scale known positive
+
+        b = floorf(fmaf(b, v.weight_scale, 0.5f)) * v.weight_inv;
+        c = floorf(fmaf(c, v.weight_scale, 0.5f)) * v.weight_inv;
     }
     const int lane = threadIdx.x & 63;
     if (need == 0) return f4{0, 0, 0, 0};                       // wave-uniform
-#if PHOTON_LINEAR_TILE_LAYERS >= 4
     {
         constexpr int TL = PHOTON_LINEAR_TILE_LAYERS;                // layers of a tile: TL - 1 cells of a column
         constexpr int NT = PHOTON_LINEAR_TILES;                      // tiles parked per wave
@@ -722,7 +563,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
                     __builtin_amdgcn_wave_barrier();
                     if (lane < 4 * TL) {
                         int l = lane;
-                        if (PIN && PHOTON_TILE_LANE_PIN) asm volatile("" : "+v"(l));   // keep the tile's lane offsets out of the march loop's live
+                        if (PIN) asm volatile("" : "+v"(l));   // keep the tile's lane offsets out of the march loop's live
                                                                 // registers: hoisted as loop invariants they were spilled, every fetch reloading them
                         const int tx = clampi(ci + (l & 1), 0, v.nx - 1), ty = clampi(cj + ((l >> 1) & 1), 0, v.ny - 1),
                                   tz = clampi(base + (l >> 2), 0, v.nz - 1);
@@ -764,45 +605,6 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         parked.ti = 0x7fffffff;                                 // to the bricks: the tiles are forgotten
         parked.ui = kIncoherent;
     }
-#else
-    {
-        // coherent wave: the 2x2x2 block of the first sampling lane serves everybody.  Lanes 0-7 fetch it and park it
-        // as four (texel, x-difference) pairs: slot 2p = texel (0,b,c), slot 2p+1 = texel (1,b,c) - texel (0,b,c) --
-        // the subtraction every lane's first-level lerp fmaf(a, t1 - t0, t0) would repeat on identical operands is done
-        // once per block by the fetching lane (same f32 operation, same bits; 16 VALU instructions fewer per sample).
-        // The blend runs on every lane, unpredicated (see tex3d_cubic_coop).
-        const Lead ld = lead_of(need, fi, fj, fk);
-        if ((same_block(ld, fi, fj, fk) & need) == need) {      // wave-uniform
-            path_stat(0);
-            if (!PHOTON_TILE_REUSE || ld.i != parked.ti || ld.j != parked.tj || ld.k != parked.tk) {  // wave-uniform: not parked yet
-                path_stat(1);
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 8) {
-                    int l = lane;
-                    if (PIN && PHOTON_TILE_LANE_PIN) asm volatile("" : "+v"(l));       // keep the tile's lane offsets out of the march loop's live
-                                                                // registers: hoisted as loop invariants they were spilled, every fetch reloading them
-                    const int ci = (int)__int_as_float(ld.i), cj = (int)__int_as_float(ld.j), ck = (int)__int_as_float(ld.k);
-                    const int tx = clampi(ci + (l & 1), 0, v.nx - 1), ty = clampi(cj + ((l >> 1) & 1), 0, v.ny - 1),
-                              tz = clampi(ck + ((l >> 2) & 1), 0, v.nz - 1);
-                    const f4 t = ldtexel(tex + (unsigned)((tz * v.ny + ty) * v.nx + tx));
-                    const f4 o = f4{pair_swap(t.x), pair_swap(t.y), pair_swap(t.z), pair_swap(t.w)};     // the pair's other texel
-                    const bool hi = (l & 1) != 0;
-                    *reinterpret_cast<float4 *>(blk + l) = make_float4(hi ? t.x - o.x : t.x, hi ? t.y - o.y : t.y,
-                                                                       hi ? t.z - o.z : t.z, hi ? t.w - o.w : t.w);
-                }
-                __builtin_amdgcn_wave_barrier();
-                parked.ti = ld.i; parked.tj = ld.j; parked.tk = ld.k;
-            }
-            // blk[tc*4 + tb*2 + {0: texel, 1: x-difference}]; same lerp tree as tex3d_linear
-            const f4 c00 = lerp4d(ldtexel(blk), ldtexel(blk + 1), a), c10 = lerp4d(ldtexel(blk + 2), ldtexel(blk + 3), a);
-            const f4 c01 = lerp4d(ldtexel(blk + 4), ldtexel(blk + 5), a), c11 = lerp4d(ldtexel(blk + 6), ldtexel(blk + 7), a);
-            const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
-            const f4 acc = lerp4(c0, c1, c);
-            __builtin_amdgcn_wave_barrier();
-            return acc;
-        }
-    }
-#endif
     // incoherent wave: bricks of 8x8x2 texels around the first unserved lane (two loads per lane); every lane
     // whose block starts within [-3, +3] texels of it in x and y (same z) blends from there in one pass
     const int bi = (int)fi, bj = (int)fj, bk = (int)fk;
@@ -819,7 +621,7 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
         const bool in_brick = !done && bk == ck && (unsigned)di <= 6u && (unsigned)dj <= 6u;
         path_stat(3);
         path_stat(6, (unsigned long long)__popcll(ballot(in_brick)));
-        if (!PHOTON_TILE_REUSE || ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform
+        if (ci != parked.bi || cj != parked.bj || ck != parked.bk) {        // wave-uniform: the brick is not parked yet
             path_stat(4);
             __builtin_amdgcn_wave_barrier();
             int l = lane;
@@ -906,25 +708,14 @@ __device__ __forceinline__ void count_samples(WaveCount &mc, unsigned long long 
 __device__ __forceinline__ void count_iterations(WaveCount &mc, unsigned long long m) { mc.iterations += (unsigned)__popcll(m); }
 
 // val_prev -- the last value a lane sampled, which the trilinear branches fall back on when a blend comes out below the
-// volume's minimum (.h:1056-1065) -- lives in LDS, not in registers (round 4): it is written after every sample (one
-// ds_write_b128 per lane, into the lane's own slot behind the brick) and read only in that rare repair.  Four VGPRs less
-// across the whole march loop: the trilinear RK4 kernel sits on its 96-register budget, and with the resume state of the
-// segmented march on top it spilled 15 of them into the loop.
-#if PHOTON_PREV_STASH
+// volume's minimum (.h:1056-1065): four VGPRs per lane across the march loop (a per-lane LDS slot instead was measured in
+// round 4: RK4 461 against 463-468 Mrays/s on C3; dropped).
 struct PrevVal {
-    f4 *slot;
-    __device__ __forceinline__ void init(f4 *blk, f4 v) { slot = blk + kPrevStashOffset + (threadIdx.x & 63); set(v); }
-    __device__ __forceinline__ void set(f4 v) { *reinterpret_cast<float4 *>(slot) = make_float4(v.x, v.y, v.z, v.w); }
-    __device__ __forceinline__ f4 get() const { return ldtexel(slot); }
-};
-#else
-struct PrevVal {                                                // A/B form: the value in four VGPRs, as in rounds 1-3
     f4 v;
     __device__ __forceinline__ void init(f4 *, f4 x) { v = x; }
     __device__ __forceinline__ void set(f4 x) { v = x; }
     __device__ __forceinline__ f4 get() const { return v; }
 };
-#endif
 
 // One cooperative sample + the linear branch's "n-1 below data_min" repair (.h:1056-1065).
 template <int INTERP, bool QUANT, class CNT, bool PIN = false>
@@ -937,7 +728,7 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
         const unsigned long long low = need & ballot(val.w < data_min);
         if (low != 0) {                                         // wave-uniform, rare: a blend below the volume's minimum
             const float ambient = 1.000277;
-            const f4 val_prev = prev.get();                     // the lane's last sampled value (parked in LDS)
+            const f4 val_prev = prev.get();                     // the lane's last sampled value
             const unsigned long long repair = low & ballot(val_prev.w == 0);
             if (repair != 0) {                                  // per lane, out of line: the same blend (the cooperative sampler's
                 count_samples(mc, repair);                      // own fallback), not a fourth copy of that sampler in the loop
@@ -952,21 +743,8 @@ __device__ __forceinline__ f4 sample_coop(const VolumeDev &v, const f4 *__restri
     return val;
 }
 
-// Intermediate ray dumps (save_intermediate_ray_data): position / direction at the start of each
-// of the first `slots` iterations, [ray][slot] float3, world frame.  Like the reference only the
-// trilinear branches record them (.h:784-790, 1004-1008); unlike it the ray index is bounds-checked
-// (the reference indexes a num_lightrays_save-sized buffer with the unchecked thread id).
-struct InterDump { float *pos, *dir; int slots, num_save; unsigned ray; };
-__device__ __forceinline__ void record_intermediate(const InterDump &d, int loop_ctr, f3 p, f3 q) {
-    if (d.pos != nullptr && loop_ctr < d.slots && d.ray < (unsigned)d.num_save) {
-        const size_t o = ((size_t)d.ray * d.slots + loop_ctr) * 3;
-        d.pos[o] = p.x; d.pos[o + 1] = p.y; d.pos[o + 2] = p.z;
-        d.dir[o] = q.x; d.dir[o + 1] = q.y; d.dir[o + 2] = q.z;
-    }
-}
-
 // SEGMENTED MARCH (round 4).  A launch may cut every ray's march into segments of at most `max_trips` trips of the loops
-// below, handled by different waves at different times (photon_core.hip, march_kernel): what a ray carries from one
+// below, handled by different waves at different times (march_kernel.hpp): what a ray carries from one
 // segment to the next, besides its position and direction, is exactly the loops' per-lane state -- the completed
 // iterations (loop_ctr; "first" = none yet), the `continue` spins, and for the trilinear branches the last value sampled
 // (val_prev, the repair of .h:1056-1065).  What is wave-level -- the parked tile, the trip counter -- starts afresh, and
@@ -1001,8 +779,8 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
     unsigned trips = rs.trips_base;                             // wave-uniform; no lane's loop_ctr exceeds it
     const unsigned trips_end = rs.max_trips == ~0u ? ~0u : trips + rs.max_trips;
     Parked parked = parked_none();
-    // val_prev: the last value a lane sampled (n-1 form), for the linear branch's repair: in the lane's LDS slot
-    // (PrevVal).  Updated unpredicated; the only live lanes that sit samples out are spinning ones, which have not
+    // val_prev: the last value a lane sampled (n-1 form), for the linear branch's repair (PrevVal).  Updated
+    // unpredicated; the only live lanes that sit samples out are spinning ones, which have not
     // sampled yet (a ray spins only on its first iteration, see inside_mask) -- theirs is put back to its initial zeros at
     // the end of such a trip.
     PrevVal prev{};
@@ -1093,7 +871,7 @@ __device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &r
     unsigned trips = rs.trips_base;
     const unsigned trips_end = rs.max_trips == ~0u ? ~0u : trips + rs.max_trips;
     Parked parked = parked_none();
-    PrevVal prev{};                                             // val_prev in LDS, as in rk4_coop
+    PrevVal prev{};                                             // val_prev, as in rk4_coop
     if (INTERP == 1) prev.init(blk, rs.val_prev);
     unsigned long long active = ballot(active_lane);
     unsigned long long first = active & ballot(loop_ctr == 0);

@@ -1,0 +1,474 @@
+// photon_scene.hip - scene and source handles: what start_ray_tracing uploads before its launch loop
+// (parallel_ray_tracing.cu:3132-3314) as a device-resident scene, the glibc srand(10) lens-sample table, and the
+// on-device scene generators.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "photon_internal.hpp"
+
+using namespace photon;
+
+// Light-field sources generated in HBM.
+// BOS target (generate_bos_lightfield_data, run_simulation_02.py:1328-1551): source (dot g, point j) sits at
+// (dot_x[g] + tmpl_x[j], dot_y[g] + tmpl_y[j], z); sums in double, cast to f32 like the ctypes marshalling.
+__global__ __launch_bounds__(256) void sources_bos_kernel(const double *__restrict__ dot_x, const double *__restrict__ dot_y,
+                                                          long long n_dots, const double *__restrict__ tx,
+                                                          const double *__restrict__ ty, int n_tmpl, double z, double radiance,
+                                                          float *sx, float *sy, float *sz, double *srad, int *sdia) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dots * n_tmpl) return;
+    const long long g = i / n_tmpl;
+    const int j = (int)(i % n_tmpl);
+    sx[i] = (float)(dot_x[g] + tx[j]);
+    sy[i] = (float)(dot_y[g] + ty[j]);
+    sz[i] = (float)z;
+    srad[i] = radiance;
+    sdia[i] = 1;                                                        // run_simulation_02.py:1544
+}
+
+// PIV particle field (run_simulation_02.py:774-996): X, Y, Z uniform in the box, radiance = the laser
+// sheet's Gaussian profile in Z, Z shifted to the object plane.  The reference draws from numpy's unseeded
+// generator; here particle i takes the four words of Philox(seed, i) -- any particle can be regenerated.
+struct PivFieldDev {
+    double lo[3], hi[3];
+    double z_object, coef, two_sigma2;      // coef = irradiance_constant / (sigma sqrt(2 pi))
+    int n_diameters;                        // 0: diameter_index = 1 (run_simulation_02.py:992)
+};
+__global__ __launch_bounds__(256) void sources_piv_kernel(unsigned long long seed, long long n, PivFieldDev f,
+                                                          const double *__restrict__ diameter_cdf, float *sx, float *sy,
+                                                          float *sz, double *srad, int *sdia) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const photon_u32x4 r = photon_philox4x32_10(seed, (unsigned long long)i, 0u, PHOTON_STREAM_SCENE);
+    const double ux = ((double)r.x + 0.5) * (1.0 / 4294967296.0), uy = ((double)r.y + 0.5) * (1.0 / 4294967296.0);
+    const double uz = ((double)r.z + 0.5) * (1.0 / 4294967296.0), ud = ((double)r.w + 0.5) * (1.0 / 4294967296.0);
+    const double X = (f.hi[0] - f.lo[0]) * ux + f.lo[0];
+    const double Y = (f.hi[1] - f.lo[1]) * uy + f.lo[1];
+    const double Z = (f.hi[2] - f.lo[2]) * uz + f.lo[2];
+    sx[i] = (float)X;
+    sy[i] = (float)Y;
+    sz[i] = (float)(Z + f.z_object);
+    srad[i] = f.coef * photon_det_exp(-1.0 * (Z * Z / f.two_sigma2));
+    int dia = 1;
+    if (f.n_diameters > 0) {
+        dia = f.n_diameters - 1;
+        for (int d = 0; d < f.n_diameters; d++)
+            if (ud < diameter_cdf[d]) { dia = d; break; }
+    }
+    sdia[i] = dia;
+}
+
+template <typename T>
+static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
+    T *d = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    PH_CHECK(pool_malloc((void **)&d, bytes));
+    s->allocs.push_back(d);
+    if (n) PH_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = d;
+    return 0;
+}
+
+template <typename T>
+static int copy_device(photon_scene *s, const T *dev_src, size_t n, const T **dev_out) {
+    T *d = nullptr;
+    PH_CHECK(pool_malloc((void **)&d, std::max<size_t>(n, 1) * sizeof(T)));
+    s->allocs.push_back(d);
+    if (n) PH_CHECK(hipMemcpy(d, dev_src, n * sizeof(T), hipMemcpyDeviceToDevice));
+    *dev_out = d;
+    return 0;
+}
+
+// glibc rand()/srand() sequence (TYPE_3 additive-feedback generator r[i] = r[i-3] + r[i-31]),
+// re-implemented so the lens-sample table of parallel_ray_tracing.cu:3228-3235 is reproduced
+// without touching the caller's process-wide rand() state.
+static void glibc_rand_sequence(unsigned seed, int count, std::vector<int> &out) {
+    std::vector<int32_t> r(344 + count);
+    r[0] = (int32_t)seed;
+    for (int i = 1; i < 31; i++) {
+        const int64_t hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        int64_t word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        r[i] = (int32_t)word;
+    }
+    for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+    for (int i = 34; i < 344 + count; i++) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+    out.resize(count);
+    for (int i = 0; i < count; i++) out[i] = (int)((uint32_t)r[344 + i] >> 1);
+}
+
+// =============================================================================================
+// C-ABI: extension entry points
+// =============================================================================================
+extern "C" {
+
+int photon_set_device(int device) {
+    PH_CHECK(hipSetDevice(device));
+    return 0;
+}
+
+int photon_device_pci_bus_id(char *buf, int len) {
+    if (!buf || len < 16) return 1;
+    int dev = 0;
+    PH_CHECK(hipGetDevice(&dev));
+    PH_CHECK(hipDeviceGetPCIBusId(buf, len, dev));
+    return 0;
+}
+
+int photon_rand_table(int n, float *r1, float *r2) {
+    if (n < 0) return 1;
+    std::vector<int> seq;
+    glibc_rand_sequence(10u, 2 * n, seq);
+    for (int k = 0; k < n; k++) {                       // RAND_MAX = 2147483647
+        r1[k] = (float)((double)seq[2 * k] / 2147483647);
+        r2[k] = (float)((double)seq[2 * k + 1] / 2147483647);
+    }
+    return 0;
+}
+
+void photon_scene_free(photon_scene_t *s) {
+    if (!s) return;
+    // The blocks below go back to the CACHE, not to the runtime (whose hipFree would wait for the device): the next scene of
+    // the same shape may be handed them at once and overwrite them with copies on the null stream, which does not wait for
+    // kernels of this scene still running on a non-blocking stream.  So wait here; microseconds on an idle device.
+    scene_quiesce(s);
+    for (void *p : s->allocs) pool_free(p);
+    pool_free(s->ws.px);
+    pool_free(s->ws.radiance);
+    free_resume_state(s);
+    pool_free(s->d_counters);
+    pool_free(s->d_queue);
+    pool_free(s->d_profile);
+    pool_free(s->d_acc);
+    for (auto &p : s->perms) pool_free(p.d_perm);
+    photon_sort_scratch_free(&s->sort_scratch);
+    for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : s->win_events) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// light-field sources generated on the device
+// ---------------------------------------------------------------------------------------------
+void photon_sources_free(photon_sources_t *src) {
+    if (!src) return;
+    if (src->x) (void)hipFree(src->x);
+    if (src->y) (void)hipFree(src->y);
+    if (src->z) (void)hipFree(src->z);
+    if (src->radiance) (void)hipFree(src->radiance);
+    if (src->diameter_index) (void)hipFree(src->diameter_index);
+    delete src;
+}
+
+static int sources_alloc(long long n, photon_sources **out) {
+    photon_sources *src = new photon_sources();
+    src->n = n;
+    const size_t m = (size_t)std::max<long long>(n, 1);
+    if (device_malloc((void **)&src->x, m * sizeof(float)) != hipSuccess || device_malloc((void **)&src->y, m * sizeof(float)) != hipSuccess ||
+        device_malloc((void **)&src->z, m * sizeof(float)) != hipSuccess ||
+        device_malloc((void **)&src->radiance, m * sizeof(double)) != hipSuccess ||
+        device_malloc((void **)&src->diameter_index, m * sizeof(int)) != hipSuccess) {
+        fprintf(stderr, "photon: sources: device allocation failed\n");
+        photon_sources_free(src);
+        return 3;
+    }
+    *out = src;
+    return 0;
+}
+
+int photon_sources_bos(const double *dot_x, const double *dot_y, int n_dots, const double *tmpl_x, const double *tmpl_y,
+                       int n_tmpl, double z, double radiance, photon_sources_t **out) {
+    if (!out || n_dots < 0 || n_tmpl < 1 || (n_dots && (!dot_x || !dot_y)) || !tmpl_x || !tmpl_y ||
+        (long long)n_dots * n_tmpl > 0x7fffffffLL) {
+        fprintf(stderr, "photon: photon_sources_bos: bad arguments\n");
+        return 1;
+    }
+    const long long n = (long long)n_dots * n_tmpl;
+    photon_sources *src = nullptr;
+    int rc = sources_alloc(n, &src);
+    if (rc) return rc;
+    double *d_in = nullptr;                                             // dot_x | dot_y | tmpl_x | tmpl_y
+    const size_t total = 2 * (size_t)n_dots + 2 * (size_t)n_tmpl;
+    auto fail = [&](int code) { if (d_in) (void)hipFree(d_in); photon_sources_free(src); return code; };
+    if (device_malloc((void **)&d_in, total * sizeof(double)) != hipSuccess) return fail(3);
+    double *d_dx = d_in, *d_dy = d_in + n_dots, *d_tx = d_in + 2 * (size_t)n_dots, *d_ty = d_tx + n_tmpl;
+    if ((n_dots && (hipMemcpy(d_dx, dot_x, n_dots * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(d_dy, dot_y, n_dots * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) ||
+        hipMemcpy(d_tx, tmpl_x, n_tmpl * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ty, tmpl_y, n_tmpl * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(4);
+    if (n) {
+        hipLaunchKernelGGL(sources_bos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_dx, d_dy, (long long)n_dots,
+                           d_tx, d_ty, n_tmpl, z, radiance, src->x, src->y, src->z, src->radiance, src->diameter_index);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(4);
+    }
+    (void)hipFree(d_in);
+    *out = src;
+    return 0;
+}
+
+int photon_sources_piv(uint64_t seed, long long n, const double box_min[3], const double box_max[3], double z_object,
+                       double beam_fwhm, double irradiance_constant, const double *diameter_cdf, int n_diameters,
+                       photon_sources_t **out) {
+    if (!out || n < 0 || n > 0x7fffffffLL || !box_min || !box_max || !(beam_fwhm > 0) || n_diameters < 0 ||
+        (n_diameters > 0 && !diameter_cdf)) {
+        fprintf(stderr, "photon: photon_sources_piv: bad arguments\n");
+        return 1;
+    }
+    photon_sources *src = nullptr;
+    int rc = sources_alloc(n, &src);
+    if (rc) return rc;
+    PivFieldDev f;
+    for (int a = 0; a < 3; a++) { f.lo[a] = box_min[a]; f.hi[a] = box_max[a]; }
+    const double sigma = beam_fwhm / (2.0 * sqrt(2.0 * log(2.0)));     // run_simulation_02.py:961
+    f.z_object = z_object;
+    f.coef = irradiance_constant * (1.0 / (sigma * sqrt(2.0 * PHOTON_PI)));
+    f.two_sigma2 = 2.0 * (sigma * sigma);
+    f.n_diameters = n_diameters;
+    double *d_cdf = nullptr;
+    auto fail = [&](int code) { if (d_cdf) (void)hipFree(d_cdf); photon_sources_free(src); return code; };
+    if (n_diameters > 0) {
+        if (device_malloc((void **)&d_cdf, n_diameters * sizeof(double)) != hipSuccess) return fail(3);
+        if (hipMemcpy(d_cdf, diameter_cdf, n_diameters * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(4);
+    }
+    if (n) {
+        hipLaunchKernelGGL(sources_piv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (unsigned long long)seed, n, f,
+                           d_cdf, src->x, src->y, src->z, src->radiance, src->diameter_index);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(4);
+    }
+    if (d_cdf) (void)hipFree(d_cdf);
+    *out = src;
+    return 0;
+}
+
+long long photon_sources_count(const photon_sources_t *src) { return src ? src->n : -1; }
+
+int photon_sources_download(const photon_sources_t *src, float *x, float *y, float *z, double *radiance,
+                            int *diameter_index) {
+    if (!src) return 1;
+    const size_t n = (size_t)src->n;
+    if (!n) return 0;
+    if (x) PH_CHECK(hipMemcpy(x, src->x, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (y) PH_CHECK(hipMemcpy(y, src->y, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (z) PH_CHECK(hipMemcpy(z, src->z, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (radiance) PH_CHECK(hipMemcpy(radiance, src->radiance, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (diameter_index) PH_CHECK(hipMemcpy(diameter_index, src->diameter_index, n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int scene_create_impl(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                             const char *scattering_type_str, const lightfield_source_t *lsp,
+                             const photon_sources *generated, int lightray_number_per_particle, float beam_wavelength,
+                             float aperture_f_number, int num_elements, const double (*element_center)[3],
+                             const element_data_t *edp, const double (*element_plane_parameters)[4],
+                             const int *element_system_index, const camera_design_t *cam, float ray_cone_pitch_ratio,
+                             photon_scene_t **out);
+
+int photon_scene_create(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                        const char *scattering_type_str, const lightfield_source_t *lsp,
+                        int lightray_number_per_particle, float beam_wavelength, float aperture_f_number,
+                        int num_elements, const double (*element_center)[3], const element_data_t *edp,
+                        const double (*element_plane_parameters)[4], const int *element_system_index,
+                        const camera_design_t *cam, float ray_cone_pitch_ratio, photon_scene_t **out) {
+    return guarded("photon_scene_create", [&]() -> int {
+        return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, nullptr,
+                                 lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                                 edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+    });
+}
+
+int photon_scene_create_from_sources(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                                     const char *scattering_type_str, const lightfield_source_t *lsp,
+                                     const photon_sources_t *sources, int lightray_number_per_particle,
+                                     float beam_wavelength, float aperture_f_number, int num_elements,
+                                     const double (*element_center)[3], const element_data_t *edp,
+                                     const double (*element_plane_parameters)[4], const int *element_system_index,
+                                     const camera_design_t *cam, float ray_cone_pitch_ratio, photon_scene_t **out) {
+    if (!sources) {
+        fprintf(stderr, "photon: photon_scene_create_from_sources: null sources\n");
+        return 1;
+    }
+    return guarded("photon_scene_create_from_sources", [&]() -> int {
+        return scene_create_impl(lens_pitch, image_distance, sdp, scattering_type_str, lsp, sources,
+                                 lightray_number_per_particle, beam_wavelength, aperture_f_number, num_elements, element_center,
+                                 edp, element_plane_parameters, element_system_index, cam, ray_cone_pitch_ratio, out);
+    });
+}
+
+static int scene_create_impl(float lens_pitch, float image_distance, const scattering_data_t *sdp,
+                             const char *scattering_type_str, const lightfield_source_t *lsp,
+                             const photon_sources *generated, int lightray_number_per_particle, float beam_wavelength,
+                             float aperture_f_number, int num_elements, const double (*element_center)[3],
+                             const element_data_t *edp, const double (*element_plane_parameters)[4],
+                             const int *element_system_index, const camera_design_t *cam, float ray_cone_pitch_ratio,
+                             photon_scene_t **out) {
+    if (!sdp || !scattering_type_str || !lsp || !edp || !cam || !out || !element_center || !element_plane_parameters ||
+        !element_system_index) {
+        fprintf(stderr, "photon: photon_scene_create: null argument\n");
+        return 1;
+    }
+    if (num_elements < 1 || num_elements > 65536) {
+        fprintf(stderr, "photon: %d optical elements given, 1..65536 supported\n", num_elements);
+        return 1;
+    }
+    const long long n_sources = generated ? generated->n : (long long)lsp->num_particles;
+    if (lightray_number_per_particle < 1 || n_sources < 0 || n_sources > 0x7fffffffLL) {
+        fprintf(stderr, "photon: bad ray / source counts\n");
+        return 1;
+    }
+    photon_scene *s = new photon_scene();
+    SceneDev &d = s->dev;
+    int rc = 0;
+    auto bail = [&](int code) { photon_scene_free(s); return code; };
+    d.lens_pitch = lens_pitch; d.image_distance = image_distance; d.beam_wavelength = beam_wavelength;
+    d.f_number = aperture_f_number; d.ratio = ray_cone_pitch_ratio;
+    d.scattering_type = strcmp(scattering_type_str, "mie") == 0 ? 1 : 0;       // .cu:3192
+    d.rays_per_source = lightray_number_per_particle;
+    const size_t ns = (size_t)n_sources;
+    d.num_sources = (int)ns;
+    if (generated) {                                    // already in HBM: device-to-device, no host arrays
+        if ((rc = copy_device<float>(s, generated->x, ns, &d.sx))) return bail(rc);
+        if ((rc = copy_device<float>(s, generated->y, ns, &d.sy))) return bail(rc);
+        if ((rc = copy_device<float>(s, generated->z, ns, &d.sz))) return bail(rc);
+        if ((rc = copy_device<double>(s, generated->radiance, ns, &d.sradiance))) return bail(rc);
+        if ((rc = copy_device<int>(s, generated->diameter_index, ns, &d.sdia))) return bail(rc);
+    } else {
+        if ((rc = upload(s, lsp->x, ns, &d.sx))) return bail(rc);
+        if ((rc = upload(s, lsp->y, ns, &d.sy))) return bail(rc);
+        if ((rc = upload(s, lsp->z, ns, &d.sz))) return bail(rc);
+        if ((rc = upload(s, lsp->radiance, ns, &d.sradiance))) return bail(rc);
+        if ((rc = upload(s, lsp->diameter_index, ns, &d.sdia))) return bail(rc);
+    }
+    d.z_offset = lsp->z_offset; d.object_distance = lsp->object_distance;
+    memcpy(d.mie_inv_rot, sdp->inverse_rotation_matrix, sizeof d.mie_inv_rot);
+    memcpy(d.beam, sdp->beam_propagation_vector, sizeof d.beam);
+    d.num_angles = sdp->num_angles; d.num_diameters = sdp->num_diameters;
+    if (d.scattering_type) {
+        if (sdp->num_angles < 2 || sdp->num_diameters < 1 || !sdp->scattering_angle || !sdp->scattering_irradiance) {
+            fprintf(stderr, "photon: \"mie\" scattering needs an angle/irradiance table\n");
+            return bail(1);
+        }
+        if ((rc = upload(s, sdp->scattering_angle, (size_t)sdp->num_angles, &d.mie_angle))) return bail(rc);
+        if ((rc = upload(s, sdp->scattering_irradiance, (size_t)sdp->num_angles * sdp->num_diameters, &d.mie_irr)))
+            return bail(rc);
+    }
+    std::vector<float> r1(lightray_number_per_particle), r2(lightray_number_per_particle);
+    photon_rand_table(lightray_number_per_particle, r1.data(), r2.data());
+    if ((rc = upload(s, r1.data(), r1.size(), &d.r1))) return bail(rc);
+    if ((rc = upload(s, r2.data(), r2.size(), &d.r2))) return bail(rc);
+    d.num_elements = num_elements;
+    {
+        std::vector<float> centers(3 * (size_t)num_elements), planes(4 * (size_t)num_elements);
+        for (int k = 0; k < num_elements; k++) {                               // .cu:3256-3260 (f64 -> f32)
+            for (int j = 0; j < 3; j++) centers[3 * k + j] = (float)element_center[k][j];
+            for (int j = 0; j < 4; j++) planes[4 * k + j] = (float)element_plane_parameters[k][j];
+            if (k < kMaxElements) {                                            // the reference path reads these
+                d.elems[k] = edp[k];
+                for (int j = 0; j < 3; j++) d.centers[k][j] = centers[3 * k + j];
+                for (int j = 0; j < 4; j++) d.planes[k][j] = planes[4 * k + j];
+                d.sys_index[k] = element_system_index[k];
+            }
+        }
+        d.train_mode = 0;
+        d.ray_order = 0;
+        d.src_perm = nullptr;
+        d.source_base = 0;
+        d.doom_margin = 0.f;
+        s->lens_z = (float)element_center[0][2];
+        if ((rc = upload(s, edp, (size_t)num_elements, &d.all_elems))) return bail(rc);
+        if ((rc = upload(s, centers.data(), centers.size(), &d.all_centers))) return bail(rc);
+        if ((rc = upload(s, planes.data(), planes.size(), &d.all_planes))) return bail(rc);
+        if ((rc = upload(s, element_system_index, (size_t)num_elements, &d.all_sys_index))) return bail(rc);
+    }
+    d.cam = *cam;
+    d.noise = NoiseDev{0, 0, 0.f, 0.f, 0ull};
+    if (cam->x_pixel_number < 1 || cam->y_pixel_number < 1) {
+        fprintf(stderr, "photon: sensor needs at least one pixel\n");
+        return bail(1);
+    }
+    hipError_t e = pool_malloc((void **)&s->d_counters, kCounterBytes);
+    if (e == hipSuccess) e = hipMemset(s->d_counters, 0, kCounterBytes);        // the march's error word among them (scene_error_word)
+    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    e = pool_malloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
+    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    e = pool_malloc((void **)&s->d_queue, kQueues * kQueueStride * sizeof(unsigned));
+    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            s->num_cus = cus;
+    }
+    for (auto &ev : s->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) { fprintf(stderr, "photon: hipEventCreate failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
+    }
+    *out = s;
+    return 0;
+}
+
+int photon_scene_set_noise(photon_scene_t *scene, int add_pos_noise, float pos_noise_std, int add_ngrad_noise,
+                           float ngrad_noise_std, uint64_t seed) {
+    if (!scene) return 1;
+    scene->dev.noise = NoiseDev{add_pos_noise ? 1 : 0, add_ngrad_noise ? 1 : 0, pos_noise_std, ngrad_noise_std,
+                                (unsigned long long)seed};
+    return 0;
+}
+
+int photon_scene_set_source_base(photon_scene_t *s, int64_t first_source) {
+    if (!s || first_source < 0) return 1;
+    s->dev.source_base = (long long)first_source;
+    return 0;
+}
+
+int photon_scene_set_element_train(photon_scene_t *s, int mode) {
+    if (!s || (mode != 0 && mode != 1)) return 1;
+    s->dev.train_mode = mode;
+    return 0;
+}
+
+int photon_scene_set_ray_order(photon_scene_t *s, int mode) {
+    if (!s || mode < 0 || mode > 2) return 1;
+    s->ray_order_mode = mode;
+    return 0;
+}
+
+int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {
+    if (!s) return 1;
+    s->skip_doomed = on != 0;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace photon {
+
+void scene_quiesce(photon_scene *s) {
+    if (!s->launched) return;
+    (void)hipDeviceSynchronize();
+    s->launched = false;
+}
+
+void free_resume_state(photon_scene *s) {
+    if (s->ws.ctr) { pool_free(s->ws.ctr); s->ws.ctr = nullptr; }
+    if (s->ws.vprev) { pool_free(s->ws.vprev); s->ws.vprev = nullptr; }
+    s->ws.spins = nullptr; s->ws.seg_flag = nullptr;
+}
+
+int ensure_workspace(photon_scene *s, size_t rays) {
+    if (s->ws_rays >= rays) return 0;
+    scene_quiesce(s);                                           // a smaller launch of this scene may still be using the old blocks
+    if (s->ws.px) { pool_free(s->ws.px); s->ws.px = nullptr; }
+    if (s->ws.radiance) { pool_free(s->ws.radiance); s->ws.radiance = nullptr; }
+    free_resume_state(s);
+    s->ws_rays = 0;
+    float *f = nullptr;
+    PH_CHECK(pool_malloc((void **)&f, rays * 6 * sizeof(float)));
+    s->ws.px = f; s->ws.py = f + rays; s->ws.pz = f + 2 * rays;
+    s->ws.dx = f + 3 * rays; s->ws.dy = f + 4 * rays; s->ws.dz = f + 5 * rays;
+    PH_CHECK(pool_malloc((void **)&s->ws.radiance, rays * sizeof(double)));
+    s->ws_rays = rays;
+    s->ws.stride = (unsigned)rays;
+    return 0;
+}
+
+}  // namespace photon

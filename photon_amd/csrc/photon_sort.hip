@@ -1,6 +1,6 @@
 // photon_sort.hip - spatial (Morton) order of a range of light-field sources, built on the device.
 //
-// Lens-major launches (photon_core.hip, "Ray order") put 64 neighbouring sources aimed at one lens point into
+// Lens-major launches (photon_trace.hip, use_lens_major) put 64 neighbouring sources aimed at one lens point into
 // a wave; "neighbouring" = consecutive in the Morton order of (x, y) on a 2^16 x 2^16 grid over the range's
 // bounding box.  start_ray_tracing builds a new scene on every call, so the order is on the per-image path of
 // every PIV-through-volume frame: it is computed where the sources already are (HBM) -- bounding box by a

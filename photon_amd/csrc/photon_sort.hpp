@@ -1,4 +1,4 @@
-// photon_sort.hpp - what photon_core.hip and photon_sort.hip share: the sort's scratch (owned by the scene, grown on demand)
+// photon_sort.hpp - what photon_trace.hip and photon_sort.hip share: the sort's scratch (owned by the scene, grown on demand)
 // and the two entry points.  ONE definition of the struct for both translation units.
 #pragma once
 #include <hip/hip_runtime.h>

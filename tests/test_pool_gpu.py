@@ -1,4 +1,4 @@
-"""The cache of freed device blocks behind start_ray_tracing (photon_core.hip, pool_malloc / pool_free): photon's unchanged
+"""The cache of freed device blocks behind start_ray_tracing (photon_pool.hip, pool_malloc / pool_free): photon's unchanged
 Python builds every scene anew per call, so per call the library would hipMalloc and hipFree ~25 blocks, the ray-state
 workspace among them.  Blocks are recycled instead; the cache is bounded and can be emptied."""
 import os

@@ -1,4 +1,4 @@
-"""The segmented march (photon_scene_set_march_segments / PHOTON_MARCH_SEGMENTS; photon_core.hip, march_group): every
+"""The segmented march (photon_scene_set_march_segments / PHOTON_MARCH_SEGMENTS; march_kernel.hpp, march_group): every
 ray's march cut into S pieces that different waves handle at different times must return the BITS of the whole march.
 
 Forced segment counts on launches far smaller than the chip -- every piece is handed out while the previous piece of its

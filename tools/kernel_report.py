@@ -54,8 +54,10 @@ def main():
     ap.add_argument("--flags", default="")
     ap.add_argument("--loops", action="store_true")
     ap.add_argument("--keep", default=None, help="write the assembly here")
+    ap.add_argument("--unit", default="photon_march_cubic", help="translation unit under photon_amd/csrc (photon_march_cubic, photon_march_linear, "
+                                                                "photon_sensor, ...)")
     args = ap.parse_args()
-    src = os.path.join(build.CSRC, "photon_core.hip")
+    src = os.path.join(build.CSRC, args.unit + ".hip")
     with tempfile.TemporaryDirectory() as tmp:
         asm = args.keep or os.path.join(tmp, "k.s")
         cmd = [build.hipcc_path()] + build.HIPCC_FLAGS + args.flags.split() + ["--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage", src, "-o", asm]

@@ -1,4 +1,4 @@
-// micro-test: the wave-to-wave hand-off the segmented march relies on (photon_core.hip, march_group), stressed.
+// micro-test: the wave-to-wave hand-off the segmented march relies on (march_kernel.hpp, march_group), stressed.
 //
 // N groups of 64 words x A arrays; a persistent grid takes items k from one atomic queue, item k = pass k / N of group
 // k % N: wait for the group's flag to reach the pass (sc1 poll), [acquire], load the group's words, CHECK that they are
