@@ -72,7 +72,8 @@ def parse_args(argv=None):
                          "shader clock, kernel time and board power per window (does a short launch clock lower, or only ramp?)")
     ap.add_argument("--no-profile", action="store_true", help="skip the wave-timing pass (roofline.march_profile)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the GPU legs of the other BASELINE configs (gpu_other_configs)")
-    ap.add_argument("--c4", action="store_true", help="add C4 whole (1e8 rays, 512^3, ~3 s and 5 GiB of HBM) to gpu_other_configs")
+    ap.add_argument("--c4", action="store_true", help=argparse.SUPPRESS)       # C4 whole is in gpu_other_configs by default now
+    ap.add_argument("--no-c4", action="store_true", help="leave the 512^3 legs (C4 whole: 1e8 rays, ~3 s, 5 GiB of HBM; C4_eighth) out of gpu_other_configs")
     ap.add_argument("--rehearse", action="store_true",
                     help="N ranks SHARING device 0, gloo reduce of host copies: exercises the N > 1 logic of this script on a "
                          "one-GPU box (RCCL cannot put two ranks on one GPU); the line is marked as a rehearsal, not a measurement")
@@ -201,7 +202,11 @@ def cpu_baseline(call_factory, volume_path, interp, sample_rays, rays_per_source
             "through_abi": {"value": round(n_abi * rays_per_source / dt_abi * 1e-6, 5), "unit": "Mrays/s",
                             "sample": f"{n_abi * rays_per_source} rays through the start_ray_tracing-shaped entry point "
                                       f"(NRRD parse + volume build included), {dt_abi:.1f} s"},
-            "other_configs": legs}
+            "other_configs": legs,
+            "numpy_reference_context": {"value": 0.156, "unit": "Mrays/s", "measured_here": False,
+                                        "what": "BASELINE.md section 1: the reference's un-wired float64 numpy ancestors (ray generation + thick lens + "
+                                                "pixel weights, no volume, no accumulation), 1e6 rays, measured in the SURVEY container -- context only, "
+                                                "not measured on this box and not the reference's shipped path (which always calls the .so)"}}
 
 
 class PowerSampler:
@@ -303,19 +308,25 @@ def measure_counters(args, kernel_tag: str):
     return traffic, insts, detail
 
 
-def gpu_other_configs(lib, torch, workdir, with_c4):
+def gpu_other_configs(lib, torch, workdir, with_c4, headline):
     """GPU legs of the configurations the headline line does not cover (BASELINE.json configs), device
     resident like the headline: C2 (PIV, Mie, thick lens, 4-pixel splat, no volume), C3 with the trilinear sampler (the one
-    the reference executes, parallel_ray_tracing.cu:3330), C5 at a quarter of its size on one GPU (the incoherent launch:
-    full-aperture cones, lens-major order, doomed rays skipped), one GPU's eighth of C3 (the strong-scaling tail at N = 8)
-    and, on request, C4 whole.  Each leg runs for a few tenths of a second after one warm-up (3 to 200 traces: a handful of
-    short launches reads 5 % low, the clock has not settled), statistics over those traces."""
+    the reference executes, parallel_ray_tracing.cu:3330), and ONE GPU'S SHARE of every 8-GPU configuration next to the whole
+    job on this one GPU: an eighth of C3 (tricubic and trilinear: the strong-scaling tail at N = 8), an eighth of C4 (1.25e7
+    rays through the full 512^3) and C4 whole, an eighth of C5 (1.25e5 particles x 40 rays through the full 256^3: the
+    incoherent launch -- full-aperture cones, lens-major order, doomed rays skipped) and C5 whole.  Each leg runs for a few
+    tenths of a second after one warm-up (1 to 200 traces: a handful of short launches reads 5 % low, the clock has not
+    settled), statistics over those traces.  `share_of_whole` = (whole job's ms / 8) / this leg's ms: what an 8-GPU strong
+    scaling can reach before communication; `fixed_ms` = step - march kernel (ray generation, queue reset, sensor stage,
+    finalize)."""
     from photon_amd import scenes
     legs = {}
 
-    def run(name, call, interp, what, reps=3):
+    def run(name, call, interp, what, reps=3, volume=None, whole=None):
         scene = lib.scene_create(call)
-        vol = lib.volume_load_nrrd(call.density_grad_filename, interp) if call.simulate_density_gradients else None
+        vol = volume
+        if vol is None and call.simulate_density_gradients:
+            vol = lib.volume_load_nrrd(call.density_grad_filename, interp)
         H, W = call.image_shape
         img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
@@ -329,37 +340,82 @@ def gpu_other_configs(lib, torch, workdir, with_c4):
             scene.trace(img.data_ptr(), vol, algo, stream=stream)
         st = scene.stats_end(stream)
         dt = (time.perf_counter() - t0) / reps
-        legs[name] = {"workload": what, "rays": call.num_rays, "ms": round(dt * 1e3, 3), "Mrays_per_s": round(call.num_rays / dt * 1e-6, 1),
-                      "kernel_ms": round(st.march_ms / reps, 3) if vol is not None else None,
-                      "clock_mhz": round(float(st.shader_clock_mhz), 1) if vol is not None else None,
-                      "rays_marched": int(st.rays_marched // reps), "rays_on_sensor": int(st.rays_on_sensor // reps), "traces": reps}
+        leg = {"workload": what, "rays": call.num_rays, "ms": round(dt * 1e3, 3), "Mrays_per_s": round(call.num_rays / dt * 1e-6, 1),
+               "kernel_ms": round(st.march_ms / reps, 3) if vol is not None else None,
+               "fixed_ms": round(dt * 1e3 - st.march_ms / reps, 3) if vol is not None else None,
+               "clock_mhz": round(float(st.shader_clock_mhz), 1) if vol is not None else None,
+               "rays_marched": int(st.rays_marched // reps), "rays_on_sensor": int(st.rays_on_sensor // reps), "traces": reps}
+        if vol is None:                                                            # "report Mrays/s and atomics/s only"
+            leg["sensor_taps"] = int(st.sensor_taps // reps)
+            leg["atomics_per_s"] = round(st.sensor_taps / reps / dt, 1)
+            leg["atomics_what"] = ("algorithmic: the reference issues one atomicAdd per tap (parallel_ray_tracing.cu:2223-2233); the "
+                                   "wave-cooperative splat sums a wave's taps per pixel in f64 first and issues one atomic per pixel and wave")
+        if whole is not None:
+            whole_ms, whole_kernel_ms = whole
+            leg["share_of_whole"] = round(whole_ms / 8.0 / (dt * 1e3), 4)
+            if whole_kernel_ms and st.march_ms > 0:
+                leg["kernel_share_of_whole"] = round(whole_kernel_ms / 8.0 / (st.march_ms / reps), 4)
+        legs[name] = leg
         scene.free()
-        if vol is not None:
+        if vol is not None and volume is None:
             vol.free()
+        return leg
 
+    vol256 = os.path.join(workdir, "bos_256.nrrd")
     run("C2", scenes.config("C2"), 0, "PIV, 100 particles x 1e4 rays, Mie, thick lens, 4-pixel splat, no volume (one fused kernel)", reps=200)
-    run("C3_trilinear", scenes.config("C3", workdir), 1,
-        "the headline job with the trilinear sampler and the texture unit's 8-bit weights (the reference's executed path)", reps=10)
-    run("C3_eighth", scenes.bos_scene(n_dots=25, density_grad_filename=os.path.join(workdir, "bos_256.nrrd")), 2,
-        "one GPU's eighth of the headline job (1.25e6 rays, tricubic RK4): the strong-scaling tail at N = 8", reps=40)
-    run("C5_quarter", scenes.config("C5", workdir, scale=0.25), 2,
-        "Mie PIV through the volume at 1/4 size: 2.5e5 polydisperse particles x 40 rays, 161^3 tricubic RK4, full-aperture cones "
-        "(lens-major order, doomed rays skipped)", reps=8)
+    lin = run("C3_trilinear", scenes.config("C3", workdir), 1,
+              "the headline job with the trilinear sampler and the texture unit's 8-bit weights (the reference's executed path)", reps=10)
+    eighth = scenes.bos_scene(n_dots=25, density_grad_filename=vol256)
+    run("C3_eighth", eighth, 2, "one GPU's eighth of the headline job (1.25e6 rays, tricubic RK4): the strong-scaling tail at N = 8", reps=40,
+        whole=headline)
+    run("C3_trilinear_eighth", eighth, 1, "one GPU's eighth of the headline job with the trilinear sampler (the reference's executed path)", reps=100,
+        whole=(lin["ms"], lin["kernel_ms"]))
+    c5 = run("C5", scenes.config("C5", workdir), 2,
+             "C5 whole on one GPU: Mie PIV through the volume, 1e6 polydisperse particles x 40 rays = 4e7 rays, 256^3 tricubic RK4, "
+             "full-aperture cones (lens-major order over device-sorted sources, doomed rays skipped)", reps=2)
+    run("C5_eighth", scenes.config("C5", workdir, scale=0.125, volume_n=256), 2,
+        "one GPU's eighth of C5: 1.25e5 polydisperse particles x 40 rays = 5e6 rays through the full 256^3, tricubic RK4", reps=10,
+        whole=(c5["ms"], c5["kernel_ms"]))
     if with_c4:
-        run("C4", scenes.config("C4", workdir), 2, "C4 whole on one GPU: 2e5 sources x 500 = 1e8 rays, 512^3, tricubic RK4 (two launches)", reps=1)
+        # the 512^3 volume is evaluated on the device (photon_volume_gaussian: the same field scenes.bos_volume(512) writes to a
+        # file, no 512 MiB NRRD on disk, no host generation) and shared by both legs
+        n, extent, z0 = 512, 66300.0, 300000.0
+        sp = extent / (n - 1)
+        vol = lib.volume_gaussian(n, sp, (-extent / 2.0, -extent / 2.0, z0), 1.225, 0.2, (0.0, 0.0, z0 + extent / 2.0), 8.0e3, interpolation=2)
+        c4 = run("C4", scenes.bos_scene(n_dots=2000, density_grad_filename=vol256), 2,
+                 "C4 whole on one GPU: 2e5 sources x 500 = 1e8 rays, 512^3, tricubic RK4 (two launches)", reps=1, volume=vol)
+        run("C4_eighth", scenes.bos_scene(n_dots=250, density_grad_filename=vol256), 2,
+            "one GPU's eighth of C4: 2.5e4 sources x 500 = 1.25e7 rays through the full 512^3, tricubic RK4", reps=3, volume=vol,
+            whole=(c4["ms"], c4["kernel_ms"]))
+        vol.free()
     return legs
 
 
-def time_abi_call(lib, call, interp):
+def time_abi_call(lib, call, interp, devices=None):
     """What photon sees: one start_ray_tracing call for the same workload -- host structs and image in, host
-    image out, scene uploaded per call, volume cached from the previous call (PCIe-inclusive; never `value`)."""
+    image out, scene uploaded per call, volume cached from the previous call (PCIe-inclusive; never `value`).
+    devices: a PHOTON_DEVICES list -- the call shards its sources over those devices (one host thread and stream each) and
+    sums their accumulators with one gather kernel on the first; "0,0,0,0,0,0,0,0" runs the 8-shard path of an 8-GPU node on
+    this one GPU (same-device pointers through the same kernel): what the sharding itself costs over a single-device call."""
     os.environ["PHOTON_INTERP"] = "cubic" if interp == 2 else "linear"
-    lib.render(call)                                    # first call of a pair: pays the NRRD parse + volume upload
-    t0 = time.perf_counter()
-    lib.render(call)
-    dt = time.perf_counter() - t0
-    return {"ms": round(dt * 1e3, 2), "Mrays_per_s": round(call.num_rays / dt * 1e-6, 2),
-            "what": "second start_ray_tracing call through ctypes (volume cached), host image in and out"}
+    if devices:
+        os.environ["PHOTON_DEVICES"] = devices
+    try:
+        lib.render(call)                                # first call of a pair: pays the NRRD parse + volume upload
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            lib.render(call)
+            times.append(time.perf_counter() - t0)
+    finally:
+        os.environ.pop("PHOTON_DEVICES", None)
+    dt = sorted(times)[1]
+    out = {"ms": round(dt * 1e3, 2), "Mrays_per_s": round(call.num_rays / dt * 1e-6, 2),
+           "what": "start_ray_tracing through ctypes (volume cached), host image in and out; median of 3 calls after one warm-up"}
+    if devices:
+        out["devices"] = devices
+        out["what"] += "; sources sharded over PHOTON_DEVICES inside the call, accumulators summed by one gather kernel on the first device"
+    return out
 
 
 def check_against_oracle(lib, make_call, vol_path, interp):
@@ -461,7 +517,9 @@ def main():
 
     comm_dev = "cpu" if args.rehearse else "cuda"      # gloo reduces host copies in a rehearsal
 
-    def step(want_stats):
+    reduce_events = []                                  # (before, after) the reduce of every timed step, on the launch stream
+
+    def step(want_stats, timed=False):
         image.zero_()
         st = scene.trace(image.data_ptr(), volume, args.algorithm, src_begin, src_end, stream=stream, want_stats=want_stats)
         if args.rehearse and dist.is_initialized():
@@ -469,6 +527,14 @@ def main():
             reduce_image(host, 0)
             if rank == 0:
                 image.copy_(host)
+        elif timed and dist.is_initialized():
+            # the collective's own time: events either side of it on the launch stream (dist.reduce makes this stream wait for
+            # RCCL's), read after the timed region
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reduce_image(image, 0)
+            e1.record()
+            reduce_events.append((e0, e1))
         else:
             reduce_image(image, 0)
         return st
@@ -488,7 +554,7 @@ def main():
     t0 = time.perf_counter()
     march_ms, iters, samples, taps, on_sensor, marched, clock_mhz, wave_ms = 0.0, 0, 0, 0, 0, 0, 0.0, 0.0
     for _ in range(args.steps):
-        st = step(not windowed)       # HIP events bracket the march kernel on the launch stream
+        st = step(not windowed, timed=True)       # HIP events bracket the march kernel on the launch stream
         if not windowed:              # (a library without the statistics window: per-step stats, one host sync per step)
             march_ms += st.march_ms
             iters, samples, taps, on_sensor = st.rk_iterations, st.volume_samples, st.sensor_taps, st.rays_on_sensor
@@ -548,7 +614,16 @@ def main():
                                 "kernel_ms": round(stw.march_ms / max(int(stw.traces), 1), 3),
                                 "ms_per_step": round(dtw / n_w * 1e3, 3), "wave_lifetime_ms": round(float(stw.march_wave_ms), 4),
                                 "power_w": pww["median_w"] if pww else None})
+    per_rank = None
     if dist.is_initialized():
+        # the slowest rank sets the step: every rank's clock, march-kernel time, own wall time and time inside the reduce
+        reduce_ms = sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1)
+        mine = torch.tensor([clock_mhz, march_ms / max(args.steps, 1), elapsed / max(args.steps, 1) * 1e3, reduce_ms, float(rays_rank)],
+                            dtype=torch.float64, device=comm_dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [{"rank": r, "clock_mhz": round(float(g[0]), 1), "kernel_ms": round(float(g[1]), 3), "ms_per_step": round(float(g[2]), 3),
+                     "reduce_ms": round(float(g[3]), 3), "rays": int(g[4])} for r, g in enumerate(gathered)]
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -647,7 +722,8 @@ def main():
                              "peak": t["peak"], "unit": "GB/s", "frac": t["frac"]})
         others = None
         if world == 1 and not child and not args.no_other_configs:
-            others = gpu_other_configs(lib, torch, workdir, args.c4)
+            is_c3 = args.dots == 200 and args.volume == 256 and interp == 2 and args.algorithm == 2 and args.rays_per_source == 500
+            others = gpu_other_configs(lib, torch, workdir, not args.no_c4, (elapsed / args.steps * 1e3, march_ms_avg) if is_c3 else None)
         desc = (f"C3: BOS, {total_rays} rays ({job_sources} sources x {args.rays_per_source}"
                 f"{' per GPU' if not strong and world > 1 else ''}), {args.volume}^3 volume, "
                 f"{'RK4' if args.algorithm == 2 else 'Euler'}, {args.interp} sampler, "
@@ -663,13 +739,20 @@ def main():
                                       + "private images, one RCCL sum-reduce onto rank 0 per step",
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1) if not args.rehearse else 0},
             "roofline": roofline, "cpu_baseline": cpu, "gpu_other_configs": others,
+            # N > 1: every rank's march clock / kernel time / step time, and the time this rank's stream spent in the RCCL reduce
+            # (reduce_ms includes waiting for the slowest rank to arrive)
+            "per_rank": per_rank,
             "volume_build_s": round(volume_build_s, 3), "rays_on_sensor": on_sensor_total,
             # `value` counts every ray of the job; rays dropped before the march as doomed (none for BOS cones) are in
             # rays_total but not in rays_marched
             "rays_marched": marched_total,
         }
+        out["library"] = lib.version()
         if world == 1 and not os.environ.get("PHOTON_BENCH_CHILD"):
             out["abi_call"] = time_abi_call(lib, call, interp)
+            if not args.no_other_configs:
+                out["abi_call_devices8_same_gpu"] = time_abi_call(lib, call, interp, devices=",".join(["%d" % local_rank] * 8))
+                out["abi_call_devices8_same_gpu"]["over_single_call"] = round(out["abi_call_devices8_same_gpu"]["ms"] / out["abi_call"]["ms"], 4)
         do_check = args.check or (world > 1 and not child)      # every multi-GPU line carries its own parity check
         if args.rehearse:
             out["rehearsal"] = (f"{world} ranks SHARING one GPU, gloo reduce of host copies: exercises this script's N > 1 logic; "

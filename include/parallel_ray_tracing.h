@@ -250,6 +250,9 @@ int photon_scene_create(float lens_pitch, float image_distance,
                         const int *element_system_index,
                         const camera_design_t *camera_design_p, float ray_cone_pitch_ratio,
                         photon_scene_t **out);
+/* Waits for the scene's device first when a trace of this scene may still be running (its device blocks go back to the
+ * library's block cache, see photon_trim_caches, and may be handed to the next scene at once): freeing a scene right after an
+ * asynchronous photon_trace is safe on any stream. */
 void photon_scene_free(photon_scene_t *scene);
 
 /* Noise hooks of start_ray_tracing (its add_pos_noise / pos_noise_std / add_ngrad_noise /
@@ -325,7 +328,12 @@ int photon_scene_set_skip_doomed(photon_scene_t *scene, int on);
 /* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.
  * vol may be NULL (= simulate_density_gradients false).  stream: hipStream_t as void*
- * (NULL = default stream).  Asynchronous unless stats != NULL (stats forces a sync). */
+ * (NULL = default stream).  Asynchronous unless stats != NULL (stats forces a sync).
+ * Hand-off errors of a segmented march (a wave gave up waiting for the previous piece of its group, or read a stale ray
+ * state: never observed, and then the render is incomplete) are counted on the device and REPORTED where the host reads the
+ * statistics -- photon_trace with stats, photon_scene_stats_end -- which zero the count when they start and fail (non-zero
+ * return, message on stderr) when it is set.  A caller of plain asynchronous traces (stats = NULL, no window) learns of them
+ * from photon_scene_check. */
 int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_tracing_algorithm,
                  int64_t src_begin, int64_t src_end, float *d_image, void *stream,
                  photon_trace_stats_t *stats);
@@ -339,6 +347,10 @@ int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, int ray_trac
  * traces in one window, is refused. */
 int photon_scene_stats_begin(photon_scene_t *scene, void *stream);
 int photon_scene_stats_end(photon_scene_t *scene, void *stream, photon_trace_stats_t *stats);
+/* Waits for `stream` and returns 0 when no trace of this scene since the count was last zeroed (photon_trace with stats,
+ * photon_scene_stats_begin, a previous photon_scene_check) had a hand-off error, 1 (and a message on stderr) otherwise;
+ * zeroes the count. */
+int photon_scene_check(photon_scene_t *scene, void *stream);
 
 /* Wave timing of the march launches (measurement; off by default, costs a handful of atomics per wave when on).  With
  * it on, every march launch after the statistics counters were last zeroed (photon_trace with stats, or
@@ -441,10 +453,13 @@ int photon_density_gaussian_write_nrrd(const char *path, int nx, int ny, int nz,
 /* The library keeps freed scene-lifetime device blocks (ray-state workspace, source arrays, accumulators: what every
  * start_ray_tracing call allocates anew) in a cache and hands them to the next scene of the same shape, per device, up to
  * PHOTON_POOL_MAX_MB (default 4096; 0 = no cache): photon's unchanged Python pays ~1 ms of hipFree per call otherwise.
- * photon_trim_caches returns all cached blocks to the runtime. */
+ * photon_trim_caches returns all cached blocks to the runtime (the library does so itself when one of ITS allocations finds
+ * the device out of memory; another user of the device -- a framework's caching allocator -- should call it before a large
+ * allocation of its own). */
 void photon_trim_caches(void);
 
-/* Library / build identification string (static storage). */
+/* Library / build identification string (static storage): "photon-amd <version> (gfx950, HIP) <git commit>[-dirty] <flags>",
+ * <flags> = "default" or "variant[...]" with the non-default -DPHOTON_* compile-time switches of this build. */
 const char *photon_version(void);
 
 /* Device-to-device float4 streaming copy of `bytes` bytes, `reps` times: read + write rate in GB/s -- the HBM rate a

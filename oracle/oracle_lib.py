@@ -52,13 +52,24 @@ def build_oracle_fma() -> str:
     return ORACLE_FMA_SO
 
 
+ORACLE_LITERAL_SO = os.path.join(ORACLE_DIR, "libphoton_oracle_literal.so")
+
+
+def build_oracle_literal() -> str:
+    """The build with the reference's literal B-spline weight expressions (oracle/Makefile, target `literal`): a sensitivity
+    probe for the one place where oracle and product deviate from the reference's spelling together; never the reference."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s", "literal"], check=True, stdout=sys.stderr)
+    return ORACLE_LITERAL_SO
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
 class Oracle:
-    def __init__(self, contracted: bool = False):
-        self.lib = ctypes.CDLL(build_oracle_fma() if contracted else build_oracle())
+    def __init__(self, contracted: bool = False, literal_bspline: bool = False):
+        assert not (contracted and literal_bspline)
+        self.lib = ctypes.CDLL(build_oracle_fma() if contracted else build_oracle_literal() if literal_bspline else build_oracle())
         L = self.lib
         self._start = bind_start_ray_tracing(L, "oracle_start_ray_tracing",
                                              [ctypes.c_int, ctypes.c_int, ctypes.POINTER(oracle_stats_t)])

@@ -141,8 +141,16 @@ inline void bspline_weights(float f, float &w0, float &w1, float &w2, float &w3)
     const float squared = f * f;
     const float one_sqd = one_frac * one_frac;
     w0 = 1.0f / 6.0f * one_sqd * one_frac;
+#ifdef PHOTON_ORACLE_LITERAL_BSPLINE
+    // the reference's own spelling (bspline_kernel.cu:90-91), four roundings per middle weight: the `literal` build of this
+    // file (oracle/Makefile), a sensitivity probe for tests/test_oracle_golden.py::test_bspline_weight_form_sensitivity --
+    // never the parity reference
+    w1 = 2.0f / 3.0f - 0.5f * squared * (2.0f - f);
+    w2 = 2.0f / 3.0f - 0.5f * one_sqd * (2.0f - one_frac);
+#else
     w1 = fmaf(squared, fmaf(0.5f, f, -1.0f), 2.0f / 3.0f);
     w2 = fmaf(one_sqd, fmaf(0.5f, one_frac, -1.0f), 2.0f / 3.0f);
+#endif
     w3 = 1.0f / 6.0f * squared * f;
 }
 

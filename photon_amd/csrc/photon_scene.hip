@@ -59,14 +59,41 @@ __global__ __launch_bounds__(256) void sources_piv_kernel(unsigned long long see
     sdia[i] = dia;
 }
 
+// A scene's small host arrays (tables, optics, a shard's sources) travel in ONE block and one host-to-device copy: a scene
+// is built per start_ray_tracing call -- per device and call with PHOTON_DEVICES -- and thirteen synchronous copies of a
+// few kilobytes each cost more than the bytes (measured: 0.15 ms of a call).  Arrays beyond kPackLimit are copied straight
+// from the caller's memory (staging 24 MB of source coordinates through another host buffer would cost more than it saves).
+constexpr size_t kPackLimit = 256 << 10, kPackAlign = 256;
+struct UploadPack {
+    struct Item { size_t offset; const void **slot; };
+    std::vector<char> host;
+    std::vector<Item> items;
+};
 template <typename T>
-static int upload(photon_scene *s, const T *host, size_t n, const T **dev_out) {
-    T *d = nullptr;
-    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    PH_CHECK(pool_malloc((void **)&d, bytes));
+static int upload(photon_scene *s, UploadPack &pack, const T *host, size_t n, const T **dev_out) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes > kPackLimit) {
+        T *d = nullptr;
+        PH_CHECK(pool_malloc((void **)&d, bytes));
+        s->allocs.push_back(d);
+        PH_CHECK(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+        *dev_out = d;
+        return 0;
+    }
+    const size_t offset = (pack.host.size() + kPackAlign - 1) / kPackAlign * kPackAlign;
+    pack.host.resize(offset + std::max<size_t>(bytes, sizeof(T)));           // an empty array still gets a valid address
+    if (bytes) memcpy(pack.host.data() + offset, host, bytes);
+    pack.items.push_back({offset, reinterpret_cast<const void **>(dev_out)});
+    *dev_out = nullptr;
+    return 0;
+}
+static int flush_uploads(photon_scene *s, UploadPack &pack) {
+    if (pack.items.empty()) return 0;
+    char *d = nullptr;
+    PH_CHECK(pool_malloc((void **)&d, pack.host.size()));
     s->allocs.push_back(d);
-    if (n) PH_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
-    *dev_out = d;
+    PH_CHECK(hipMemcpy(d, pack.host.data(), pack.host.size(), hipMemcpyHostToDevice));
+    for (const auto &it : pack.items) *it.slot = d + it.offset;
     return 0;
 }
 
@@ -318,6 +345,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     }
     photon_scene *s = new photon_scene();
     SceneDev &d = s->dev;
+    UploadPack pack;
     int rc = 0;
     auto bail = [&](int code) { photon_scene_free(s); return code; };
     d.lens_pitch = lens_pitch; d.image_distance = image_distance; d.beam_wavelength = beam_wavelength;
@@ -333,11 +361,11 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         if ((rc = copy_device<double>(s, generated->radiance, ns, &d.sradiance))) return bail(rc);
         if ((rc = copy_device<int>(s, generated->diameter_index, ns, &d.sdia))) return bail(rc);
     } else {
-        if ((rc = upload(s, lsp->x, ns, &d.sx))) return bail(rc);
-        if ((rc = upload(s, lsp->y, ns, &d.sy))) return bail(rc);
-        if ((rc = upload(s, lsp->z, ns, &d.sz))) return bail(rc);
-        if ((rc = upload(s, lsp->radiance, ns, &d.sradiance))) return bail(rc);
-        if ((rc = upload(s, lsp->diameter_index, ns, &d.sdia))) return bail(rc);
+        if ((rc = upload(s, pack, lsp->x, ns, &d.sx))) return bail(rc);
+        if ((rc = upload(s, pack, lsp->y, ns, &d.sy))) return bail(rc);
+        if ((rc = upload(s, pack, lsp->z, ns, &d.sz))) return bail(rc);
+        if ((rc = upload(s, pack, lsp->radiance, ns, &d.sradiance))) return bail(rc);
+        if ((rc = upload(s, pack, lsp->diameter_index, ns, &d.sdia))) return bail(rc);
     }
     d.z_offset = lsp->z_offset; d.object_distance = lsp->object_distance;
     memcpy(d.mie_inv_rot, sdp->inverse_rotation_matrix, sizeof d.mie_inv_rot);
@@ -348,14 +376,14 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
             fprintf(stderr, "photon: \"mie\" scattering needs an angle/irradiance table\n");
             return bail(1);
         }
-        if ((rc = upload(s, sdp->scattering_angle, (size_t)sdp->num_angles, &d.mie_angle))) return bail(rc);
-        if ((rc = upload(s, sdp->scattering_irradiance, (size_t)sdp->num_angles * sdp->num_diameters, &d.mie_irr)))
+        if ((rc = upload(s, pack, sdp->scattering_angle, (size_t)sdp->num_angles, &d.mie_angle))) return bail(rc);
+        if ((rc = upload(s, pack, sdp->scattering_irradiance, (size_t)sdp->num_angles * sdp->num_diameters, &d.mie_irr)))
             return bail(rc);
     }
     std::vector<float> r1(lightray_number_per_particle), r2(lightray_number_per_particle);
     photon_rand_table(lightray_number_per_particle, r1.data(), r2.data());
-    if ((rc = upload(s, r1.data(), r1.size(), &d.r1))) return bail(rc);
-    if ((rc = upload(s, r2.data(), r2.size(), &d.r2))) return bail(rc);
+    if ((rc = upload(s, pack, r1.data(), r1.size(), &d.r1))) return bail(rc);
+    if ((rc = upload(s, pack, r2.data(), r2.size(), &d.r2))) return bail(rc);
     d.num_elements = num_elements;
     {
         std::vector<float> centers(3 * (size_t)num_elements), planes(4 * (size_t)num_elements);
@@ -375,11 +403,12 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         d.source_base = 0;
         d.doom_margin = 0.f;
         s->lens_z = (float)element_center[0][2];
-        if ((rc = upload(s, edp, (size_t)num_elements, &d.all_elems))) return bail(rc);
-        if ((rc = upload(s, centers.data(), centers.size(), &d.all_centers))) return bail(rc);
-        if ((rc = upload(s, planes.data(), planes.size(), &d.all_planes))) return bail(rc);
-        if ((rc = upload(s, element_system_index, (size_t)num_elements, &d.all_sys_index))) return bail(rc);
+        if ((rc = upload(s, pack, edp, (size_t)num_elements, &d.all_elems))) return bail(rc);
+        if ((rc = upload(s, pack, centers.data(), centers.size(), &d.all_centers))) return bail(rc);
+        if ((rc = upload(s, pack, planes.data(), planes.size(), &d.all_planes))) return bail(rc);
+        if ((rc = upload(s, pack, element_system_index, (size_t)num_elements, &d.all_sys_index))) return bail(rc);
     }
+    if ((rc = flush_uploads(s, pack))) return bail(rc);
     d.cam = *cam;
     d.noise = NoiseDev{0, 0, 0.f, 0.f, 0ull};
     if (cam->x_pixel_number < 1 || cam->y_pixel_number < 1) {

@@ -302,6 +302,12 @@ extern "C" int photon_scene_stats_begin(photon_scene_t *scene, void *stream_p) {
     });
 }
 
+extern "C" int photon_scene_check(photon_scene_t *scene, void *stream_p) {
+    if (!scene) return 1;
+    PH_CHECK(hipStreamSynchronize((hipStream_t)stream_p));
+    return march_error_check(scene);
+}
+
 extern "C" int photon_scene_stats_end(photon_scene_t *scene, void *stream_p, photon_trace_stats_t *stats) {
     if (!scene || !stats || !scene->win_open) {
         fprintf(stderr, "photon: photon_scene_stats_end: no open statistics window\n");

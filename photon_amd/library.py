@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = (
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
     "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_chunk", "photon_march_queue_size",
     "photon_scene_set_march_segments", "photon_march_segments_plan", "photon_trim_caches", "photon_trace",
-    "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_set_march_profile", "photon_scene_march_profile", "photon_scene_march_profile_raw",
+    "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_check", "photon_scene_set_march_profile", "photon_scene_march_profile", "photon_scene_march_profile_raw",
     "photon_trace_volume_rays", "photon_trace_volume_rays_queued", "photon_version",
     # section 3: scene generation on the device
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
@@ -443,6 +443,12 @@ class Scene:
         self._lib._check(self._lib.lib.photon_scene_stats_end(self.handle, ctypes.c_void_p(int(stream)) if stream else None,
                                                               ctypes.byref(stats)), "photon_scene_stats_end")
         return stats
+
+    def check(self, stream: int = 0):
+        """Wait for `stream`; raise if a trace of this scene had a hand-off error between march segments (photon_scene_check)."""
+        f = self._lib.lib.photon_scene_check
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._lib._check(f(self.handle, ctypes.c_void_p(int(stream)) if stream else None), "photon_scene_check")
 
     def set_march_segments(self, segments: int):
         """-1 the library's choice, 1 whole marches, n: cut every march of a large launch into n segments (speed only)."""

@@ -43,17 +43,28 @@ def test_bench_line_contract(photon):
     p = r["march_profile"]                               # wave timing of the launch: start-up, span, drain
     assert p["launches"] == 2 and p["waves"] > 0 and p["span_ms"] > 0 and 0 <= p["drain_ms"] < p["span_ms"]
     o = d["gpu_other_configs"]                           # the other BASELINE configs, GPU legs
-    assert set(o) == {"C2", "C3_trilinear", "C3_eighth", "C5_quarter"}
+    # one GPU's share of every 8-GPU configuration next to the whole job on this GPU
+    assert set(o) == {"C2", "C3_trilinear", "C3_eighth", "C3_trilinear_eighth", "C5", "C5_eighth", "C4", "C4_eighth"}
     assert o["C2"]["rays"] == 1000000 and o["C2"]["kernel_ms"] is None and o["C2"]["rays_on_sensor"] > 0
-    for k in ("C3_trilinear", "C3_eighth", "C5_quarter"):
-        assert o[k]["ms"] > 0 and o[k]["kernel_ms"] > 0 and o[k]["clock_mhz"] > 500 and o[k]["rays_marched"] > 0, k
-    assert o["C5_quarter"]["rays_marched"] < o["C5_quarter"]["rays"]           # doomed rays were skipped
+    assert o["C2"]["atomics_per_s"] > 1e9 and o["C2"]["sensor_taps"] > 3 * o["C2"]["rays_on_sensor"]         # four taps per ray that lands
+    for k in set(o) - {"C2"}:
+        assert o[k]["ms"] > 0 and o[k]["kernel_ms"] > 0 and o[k]["clock_mhz"] > 500 and o[k]["rays_marched"] > 0 and o[k]["fixed_ms"] > 0, k
+    assert (o["C4"]["rays"], o["C4_eighth"]["rays"], o["C5"]["rays"], o["C5_eighth"]["rays"]) == (100_000_000, 12_500_000, 40_000_000, 5_000_000)
+    assert o["C5_eighth"]["rays_marched"] < o["C5_eighth"]["rays"]             # doomed rays were skipped
+    for k in ("C3_trilinear_eighth", "C5_eighth", "C4_eighth"):                # (the headline here is not C3: no share for C3_eighth)
+        assert 0.5 < o[k]["share_of_whole"] <= 1.1 and 0.5 < o[k]["kernel_share_of_whole"] <= 1.1, (k, o[k])
+    assert "share_of_whole" not in o["C3_eighth"]
+    assert d["library"].startswith("photon-amd") and ("default" in d["library"] or "variant[" in d["library"])
     # measured in this run by the child rocprofv3 passes, not read from a file
     assert isinstance(r["traffic"], int) and r["traffic"] > 0 and r["hbm"]["source"].startswith("measured in this run")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert d["check"]["rel_l2"] <= 1e-5
     assert d["abi_call"]["ms"] > 0
+    a8 = d["abi_call_devices8_same_gpu"]                  # the 8-shard path of an 8-GPU node, on this one GPU
+    assert a8["devices"] == "0,0,0,0,0,0,0,0" and a8["ms"] > 0 and 0.5 < a8["over_single_call"] < 3.0
+    assert d["cpu_baseline"]["numpy_reference_context"]["value"] == 0.156 and d["cpu_baseline"]["numpy_reference_context"]["measured_here"] is False
+    assert d["per_rank"] is None
 
 
 @pytest.mark.gpu
@@ -76,6 +87,9 @@ def test_bench_rehearsal_three_ranks_on_one_gpu(photon):
     assert d["rays_on_sensor"] == 6 * 100 * 500
     assert d["check"]["sources"] == 600 and d["check"]["rel_l2"] <= 1e-5
     assert d["check"]["sharded_vs_single_gpu_rel_l2"] <= 1e-6                    # what every real N > 1 line carries too
+    pr = d["per_rank"]                                   # every rank's clock / kernel time / step time: the slowest sets the step
+    assert [r["rank"] for r in pr] == [0, 1, 2] and all(r["clock_mhz"] > 500 and r["kernel_ms"] > 0 and r["ms_per_step"] > 0 for r in pr)
+    assert sum(r["rays"] for r in pr) == 6 * 100 * 500
     w = _bench("--gpus", "2", "--rehearse", "--scaling", "weak", "--cpu-sample-rays", "0", "--no-traffic")
     assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["config"]["rays_total"] == 2 * 6 * 100 * 500
     assert w["check"]["sharded_vs_single_gpu_rel_l2"] <= 1e-6                    # two different scenes, summed

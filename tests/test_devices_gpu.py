@@ -1,0 +1,62 @@
+"""PHOTON_DEVICES: the sources of ONE start_ray_tracing call sharded over several devices (photon_abi.hip,
+render_on_devices) -- what is distributed is the reference's chunk loop over light-field sources
+(parallel_ray_tracing.cu:3505-3558), and the per-device accumulators are summed on the first device by one gather kernel
+reading the others through their peer-mapped pointers.  On this box every listed device is GPU 0 (same-device pointers
+through the same kernel): the code path of an 8-GPU node, its image, and what the sharding costs over a single call."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from photon_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _median_ms(photon, call, reps=3):
+    photon.render(call)                                      # warm-up: volume cached, blocks in the cache
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        img = photon.render(call)
+        times.append((time.perf_counter() - t0) * 1e3)
+    return sorted(times)[len(times) // 2], img
+
+
+@pytest.mark.parametrize("interp", ["cubic", "linear"])
+def test_eight_shards_on_one_gpu_cost_and_image(photon, workdir, monkeypatch, interp):
+    """The headline job (C3: 1e7 rays, 256^3) through start_ray_tracing as ONE call and as EIGHT shards side by side
+    (PHOTON_DEVICES=0 x 8: eight host threads, eight scenes with shard-only uploads, eight streams, one gather-and-sum):
+    same image (f64 accumulation; the shards only change the summation order), and the 8-shard call costs at most 5 %
+    + 0.5 ms more than the single call -- the per-call price of the multi-device path itself."""
+    monkeypatch.setenv("PHOTON_INTERP", interp)
+    monkeypatch.delenv("PHOTON_DEVICES", raising=False)
+    call = scenes.config("C3", workdir)
+    assert call.num_rays == 10_000_000
+    one_ms, one = _median_ms(photon, call)
+    monkeypatch.setenv("PHOTON_DEVICES", "0,0,0,0,0,0,0,0")
+    many_ms, many = _median_ms(photon, call)
+    rel = np.linalg.norm(many.astype(np.float64) - one) / np.linalg.norm(one.astype(np.float64))
+    assert rel <= 1e-6, rel
+    assert many_ms <= 1.05 * one_ms + 0.5, (one_ms, many_ms)
+
+
+def test_seventeen_shards_chain_the_gather(photon, oracle, workdir, monkeypatch):
+    """More accumulators than one gather launch takes (15 peers): the sum is chained, the last launch folds it into the
+    caller's image -- which is read-modify-write (parallel_ray_tracing.cu:3309, 3675): a non-zero image comes back with
+    the render ADDED.  Against the oracle."""
+    rho, sp, org = scenes.bos_volume(32)
+    path = scenes.write_nrrd(os.path.join(workdir, "dev32.nrrd"), rho, sp, org)
+    call = scenes.bos_scene(n_dots=9, points_per_dot=15, rays_per_source=100, density_grad_filename=path)
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    ref, _ = oracle.render(call, interpolation=2)
+    monkeypatch.setenv("PHOTON_DEVICES", ",".join(["0"] * 17))
+    start = np.zeros(call.image_shape, np.float32)
+    start[:8, :8] = 1.0                                      # a corner no BOS dot reaches: must come back untouched
+    assert ref[:8, :8].max() == 0.0
+    got = photon.render(call, image=start.copy()).astype(np.float64)
+    assert (got[:8, :8] == 1.0).all()
+    got[:8, :8] = 0.0
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel <= 1e-5, rel

@@ -621,3 +621,53 @@ def test_fma_contraction_sensitivity(oracle, tmp_path):
     for name, v in measured.items():
         assert 0 < v < 5e-4, (name, v)          # expected agreement with an NVIDIA run of the reference <~ 1e-3
     assert measured["c3_slice"] < 1e-4          # the march is far less sensitive than the f32 lens solve
+
+
+def test_bspline_weight_form_sensitivity(oracle, tmp_path):
+    """The one place where oracle and product left the reference's SPELLING together (round 3): the tricubic sampler's two
+    middle B-spline weights are evaluated in the Horner form fmaf(f^2, fmaf(0.5, f, -1), 2/3) -- two roundings -- where the
+    reference writes 2/3 - 0.5 f^2 (2 - f) (CubicInterpolationCUDA/code/internal/bspline_kernel.cu:90-91: four).  Equal
+    in exact arithmetic, and the reference never executes this sampler (interpolation_scheme is hard-wired to trilinear,
+    parallel_ray_tracing.cu:3330), so no reference bits exist either way -- but an oracle edit that accompanies a kernel edit
+    on an unpinned row has to be BOUNDED: a third build of the same oracle source with the literal
+    expressions (oracle/Makefile, target `literal`) against the shipped form, on the sampler's anchor case and on the three
+    image cases of test_fma_contraction_sensitivity that go through the tricubic sampler.  Measured: sampler outputs differ
+    by at most 1.1 ulp of the largest tap, the f64 anchor is met by both forms, and the images differ by 1.9e-8 .. 3.2e-8
+    relative L2 (asserted: < 1e-6) -- three orders below the contraction bound of test_fma_contraction_sensitivity."""
+    from oracle_lib import Oracle
+    literal = Oracle(literal_bspline=True)
+
+    def rel(x, y):
+        x, y = x.astype(np.float64), y.astype(np.float64)
+        return np.linalg.norm(x - y) / np.linalg.norm(x)
+
+    # (1) the sampler itself, on the anchor case: both forms against the f64 evaluation, and against each other
+    rho, coords = tricubic_anchor_case()
+    got = {}
+    for name, o in (("shipped", oracle), ("literal", literal)):
+        v = o.volume_from_density(rho, (100.0, 100.0, 100.0), (0.0, 0.0, 750e3), 2)
+        coeffs = v.download(True)
+        got[name] = v.sample(coords).astype(np.float64)
+        scale = np.abs(coeffs.reshape(-1, 4)).max(axis=0)
+        err = np.abs(got[name] - tricubic_f64(coeffs, coords)) / scale
+        assert err.max() < 8 * 2.0 ** -24, (name, err.max())
+        v.free()
+    form_ulp = (np.abs(got["shipped"] - got["literal"]) / scale).max() / 2.0 ** -24
+    assert 0 < form_ulp <= 4, form_ulp                        # the forms DO differ (a vacuous test would read 0), by roundings only
+    # (2) images through the tricubic sampler: slices of C3 (256^3) and a small volume with a steep blob
+    measured = {"sampler_max_ulp_of_largest_tap": form_ulp}
+    rho, sp, org = scenes.bos_volume(256)
+    path = scenes.write_nrrd(str(tmp_path / "c3.nrrd"), rho, sp, org)
+    call = scenes.bos_scene(n_dots=200, points_per_dot=100, rays_per_source=500, density_grad_filename=path, seed=1)
+    for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+        setattr(call, f, getattr(call, f)[:20])
+    measured["c3_slice_rk4"] = rel(oracle.render(call, interpolation=2)[0], literal.render(call, interpolation=2)[0])
+    call.ray_tracing_algorithm = 1
+    measured["c3_slice_euler"] = rel(oracle.render(call, interpolation=2)[0], literal.render(call, interpolation=2)[0])
+    rho, sp, org = scenes.bos_volume(48)
+    path = scenes.write_nrrd(str(tmp_path / "v48.nrrd"), rho, sp, org)
+    call = scenes.bos_scene(n_dots=12, points_per_dot=40, rays_per_source=200, density_grad_filename=path, seed=5)
+    measured["v48_rk4"] = rel(oracle.render(call, interpolation=2)[0], literal.render(call, interpolation=2)[0])
+    print("B-spline weight form sensitivity:", {k: f"{v:.2e}" for k, v in measured.items()})
+    for name in ("c3_slice_rk4", "c3_slice_euler", "v48_rk4"):
+        assert measured[name] < 1e-6, (name, measured[name])
