@@ -370,12 +370,19 @@ def gpu_other_configs(lib, torch, workdir, with_c4, headline):
         whole=headline)
     run("C3_trilinear_eighth", eighth, 1, "one GPU's eighth of the headline job with the trilinear sampler (the reference's executed path)", reps=100,
         whole=(lin["ms"], lin["kernel_ms"]))
-    c5 = run("C5", scenes.config("C5", workdir), 2,
+    c5_call = scenes.config("C5", workdir)
+    c5 = run("C5", c5_call, 2,
              "C5 whole on one GPU: Mie PIV through the volume, 1e6 polydisperse particles x 40 rays = 4e7 rays, 256^3 tricubic RK4, "
              "full-aperture cones (lens-major order over device-sorted sources, doomed rays skipped)", reps=2)
-    run("C5_eighth", scenes.config("C5", workdir, scale=0.125, volume_n=256), 2,
-        "one GPU's eighth of C5: 1.25e5 polydisperse particles x 40 rays = 5e6 rays through the full 256^3, tricubic RK4", reps=10,
-        whole=(c5["ms"], c5["kernel_ms"]))
+    # what rank 0 of 8 gets: shard_range(1e6, 0, 8) = the leading eighth of the job's source list (sorted by coarse xy tile, so a
+    # compact strip of the field at the job's own particle density) -- NOT a sparser field of 1.25e5 particles spread over the
+    # whole field of view, whose lens-major waves span 2.8x wider patches and march at half the rate
+    n_eighth = c5_call.num_sources // 8
+    for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
+        setattr(c5_call, f, getattr(c5_call, f)[:n_eighth])
+    run("C5_eighth", c5_call, 2,
+        "one GPU's eighth of C5: the leading 1.25e5 of the job's 1e6 polydisperse particles x 40 rays = 5e6 rays through the full 256^3, "
+        "tricubic RK4", reps=10, whole=(c5["ms"], c5["kernel_ms"]))
     if with_c4:
         # the 512^3 volume is evaluated on the device (photon_volume_gaussian: the same field scenes.bos_volume(512) writes to a
         # file, no 512 MiB NRRD on disk, no host generation) and shared by both legs

@@ -62,14 +62,25 @@ def build_oracle_literal() -> str:
     return ORACLE_LITERAL_SO
 
 
+ORACLE_LIBM_ERF_SO = os.path.join(ORACLE_DIR, "libphoton_oracle_libm_erf.so")
+
+
+def build_oracle_libm_erf() -> str:
+    """The build whose erf splat calls glibc's erf() instead of photon_det_erf (oracle/Makefile, target `libm_erf`): a
+    sensitivity probe; never the reference."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s", "libm_erf"], check=True, stdout=sys.stderr)
+    return ORACLE_LIBM_ERF_SO
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
 class Oracle:
-    def __init__(self, contracted: bool = False, literal_bspline: bool = False):
-        assert not (contracted and literal_bspline)
-        self.lib = ctypes.CDLL(build_oracle_fma() if contracted else build_oracle_literal() if literal_bspline else build_oracle())
+    def __init__(self, contracted: bool = False, literal_bspline: bool = False, libm_erf: bool = False):
+        assert contracted + literal_bspline + libm_erf <= 1
+        self.lib = ctypes.CDLL(build_oracle_fma() if contracted else build_oracle_literal() if literal_bspline
+                               else build_oracle_libm_erf() if libm_erf else build_oracle())
         L = self.lib
         self._start = bind_start_ray_tracing(L, "oracle_start_ray_tracing",
                                              [ctypes.c_int, ctypes.c_int, ctypes.POINTER(oracle_stats_t)])
@@ -131,6 +142,22 @@ class Oracle:
         r1, r2 = np.empty(n, np.float32), np.empty(n, np.float32)
         self.lib.oracle_rand_table(n, _p(r1), _p(r2))
         return r1, r2
+
+    def det_erf(self, x):
+        """photon_det_erf (include/photon_det_math.h) as this build evaluates it."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        self.lib.oracle_det_erf.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.oracle_det_erf(int(x.size), _p(x), _p(out))
+        return out
+
+    def det_div_rcp_mismatches(self, a, b: float) -> int:
+        """How many of a[i] / b differ from photon_det_div_rcp(a[i], b, 1 / b)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        f = self.lib.oracle_det_div_rcp_mismatches
+        f.restype = ctypes.c_longlong
+        f.argtypes = [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_double]
+        return int(f(int(a.size), _p(a), float(b)))
 
     def det_eval(self, fn: int, x):
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -1119,6 +1119,14 @@ struct alignas(64) Image {          // per-thread double accumulator (a cache li
 
 // Gaussian-spot (erf) splat shared by intersect_sensor_02 (.cu:1383-1543, render_fraction
 // 0.75) and create_apparent_image (.cu:1545-1733, render_fraction 1.0).
+// erf: the reference calls CUDA's erf(double).  Oracle and product share photon_det_erf (include/photon_det_math.h: absolute
+// error <= 4e-16) since round 5 -- before, the oracle used glibc's and the product ocml's.  The `libm_erf` build of this file
+// (oracle/Makefile) keeps glibc's: tests/test_oracle_golden.py::test_erf_form_sensitivity bounds one against the other.
+#ifdef PHOTON_ORACLE_LIBM_ERF
+#define ORACLE_ERF(x) erf(x)
+#else
+#define ORACLE_ERF(x) photon_det_erf(x)
+#endif
 void erf_splat(Image &img, float d_x, float d_y, double radiance, f3 dir, float D, float render_fraction) {
     const double pi = 3.141592653589793;
     const float alpha = photon_det_atanf(sqrtf((dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
@@ -1135,8 +1143,8 @@ void erf_splat(Image &img, float d_x, float d_y, double radiance, f3 dir, float 
                                 rad <= render_fraction * D;
             if (!render) continue;
             const float inc = (float)(I0 * pi / 32.0 *
-                                      (erf(sqrt8 * (col - X - 0.5) / D) - erf(sqrt8 * (col - X + 0.5) / D)) *
-                                      (erf(sqrt8 * (row - Y - 0.5) / D) - erf(sqrt8 * (row - Y + 0.5) / D)));
+                                      (ORACLE_ERF(sqrt8 * (col - X - 0.5) / D) - ORACLE_ERF(sqrt8 * (col - X + 0.5) / D)) *
+                                      (ORACLE_ERF(sqrt8 * (row - Y - 0.5) / D) - ORACLE_ERF(sqrt8 * (row - Y + 0.5) / D)));
             img.acc[(size_t)row * img.W + col] += inc;
             img.taps++;
         }
@@ -1712,6 +1720,20 @@ void oracle_set_num_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);
 #endif
+}
+
+// photon_det_div_rcp against the division it replaces in the product's erf splat (tests/test_det_math.py): number of
+// quotients a[i] / b that differ
+long long oracle_det_div_rcp_mismatches(long long n, const double *a, double b) {
+    const double rb = 1.0 / b;
+    long long bad = 0;
+    for (long long i = 0; i < n; i++) bad += !(photon_det_div_rcp(a[i], b, rb) == a[i] / b);
+    return bad;
+}
+
+// photon_det_erf as this build of the header evaluates it (tests/test_det_math.py)
+void oracle_det_erf(int n, const double *x, double *out) {
+    for (int i = 0; i < n; i++) out[i] = photon_det_erf(x[i]);
 }
 
 int oracle_num_threads(void) {

@@ -407,7 +407,7 @@ __device__ __forceinline__ SplatReq erf_splat_prepare(bool valid, float d_x, flo
 }
 
 __device__ __forceinline__ double erf_edge_diff(float sqrt8, int idx, float centre, float D) {
-    return erf(sqrt8 * (idx - centre - 0.5) / D) - erf(sqrt8 * (idx - centre + 0.5) / D);
+    return photon_det_erf(sqrt8 * (idx - centre - 0.5) / D) - photon_det_erf(sqrt8 * (idx - centre + 0.5) / D);
 }
 
 // per-lane form (fallback): one atomic per rendered pixel
@@ -458,9 +458,10 @@ __device__ __forceinline__ int wave_max_i(int v) { return wave_minmax_i<true>(v)
 // ---------------------------------------------------------------------------------------------
 constexpr int kSplatTiles = 6;
 constexpr int kSplatSlots = 7;              // columns / rows of one ray's window the parked layout carries (D = 3: 6 or 7)
+constexpr unsigned kSplatStride = 2 * kSplatSlots * sizeof(double);      // bytes between the parked factors of consecutive rays
 
 struct SplatLds {                           // one wave's area: 8 KiB (five 256-thread blocks per CU)
-    float4 head[64];                        // erf: X, Y, bits(c0), r0 | nw << 20 | nh << 24   4-pixel: bits(ii), bits(jj), inc0, inc1
+    float4 head[64];                        // 4-pixel splat: bits(ii), bits(jj), inc0, inc1 (the erf splat reads its rays' windows from registers)
     double f[64][2 * kSplatSlots];          // erf: scale * d_erf(column c0 + j), j < 7 | d_erf(row r0 + j)   4-pixel: [0] = inc2, inc3
 };
 
@@ -472,6 +473,8 @@ __device__ __forceinline__ float sqrt_threshold(float r) {
     while (sqrtf(__uint_as_float(__float_as_uint(t) + 1u)) <= r) t = __uint_as_float(__float_as_uint(t) + 1u);
     return t;
 }
+
+__device__ __forceinline__ bool lane_of_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 // Must be called by all 64 lanes of the wave.  Returns this lane's share of the number of rendered pixels (the wave's
 // total is what the callers accumulate).
@@ -498,12 +501,15 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
     if (q.valid) {
         const bool exact_x = q.X >= 8.0f, exact_y = q.Y >= 8.0f;
         double *fx = lds.f[lane], *fy = lds.f[lane] + kSplatSlots;
+        // the reference's sqrt8 * (idx - X -+ 0.5) / D: the quotients through the reciprocal of D (photon_det_div_rcp: the same
+        // correctly rounded values as the divisions, three operations each instead of eleven)
+        const double Dd = q.D, rD = 1.0 / Dd;
         if (exact_x) {
-            double lo = erf(sqrt8 * (q.c0 - q.X - 0.5) / q.D);
+            double lo = photon_det_erf(photon_det_div_rcp(sqrt8 * (q.c0 - q.X - 0.5), Dd, rD));
 #pragma unroll
             for (int j = 0; j < kSplatSlots; j++) {
                 if (j < nw) {
-                    const double hi = erf(sqrt8 * (q.c0 + j - q.X + 0.5) / q.D);
+                    const double hi = photon_det_erf(photon_det_div_rcp(sqrt8 * (q.c0 + j - q.X + 0.5), Dd, rD));
                     fx[j] = q.scale * (lo - hi);
                     lo = hi;
                 }
@@ -514,11 +520,11 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
                 if (j < nw) fx[j] = q.scale * erf_edge_diff(sqrt8, q.c0 + j, q.X, q.D);
         }
         if (exact_y) {
-            double lo = erf(sqrt8 * (q.r0 - q.Y - 0.5) / q.D);
+            double lo = photon_det_erf(photon_det_div_rcp(sqrt8 * (q.r0 - q.Y - 0.5), Dd, rD));
 #pragma unroll
             for (int j = 0; j < kSplatSlots; j++) {
                 if (j < nh) {
-                    const double hi = erf(sqrt8 * (q.r0 + j - q.Y + 0.5) / q.D);
+                    const double hi = photon_det_erf(photon_det_div_rcp(sqrt8 * (q.r0 + j - q.Y + 0.5), Dd, rD));
                     fy[j] = lo - hi;
                     lo = hi;
                 }
@@ -528,40 +534,104 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
             for (int j = 0; j < kSplatSlots; j++)
                 if (j < nh) fy[j] = erf_edge_diff(sqrt8, q.r0 + j, q.Y, q.D);
         }
-        lds.head[lane] = make_float4(q.X, q.Y, __int_as_float(q.c0), __int_as_float((q.r0 & 0xfffff) | (nw << 20) | (nh << 24)));
+    }
+    // ---- which pixels of its window this ray renders, as a bit pattern: bit 8 jy + jx <-> pixel (c0 + jx, r0 + jy), set when
+    // the pixel lies in the window, in the image and within the render radius -- sqrtf((col - X)^2 + (row - Y)^2) <= rfD,
+    // the reference's test (.cu:1504), as rad2 <= rad2_max.  49 tests per RAY, here, instead of one per ray AND pixel lane in
+    // the loop below.
+    unsigned long long pattern = 0;
+    if (q.valid) {
+        float dx2[kSplatSlots];
+        unsigned col_ok = 0;
+#pragma unroll
+        for (int jx = 0; jx < kSplatSlots; jx++) {
+            const int col = q.c0 + jx;
+            dx2[jx] = (col - q.X) * (col - q.X);
+            col_ok |= (jx < nw && col >= 0 && col <= W - 1) ? 1u << jx : 0u;
+        }
+#pragma unroll
+        for (int jy = 0; jy < kSplatSlots; jy++) {
+            const int row = q.r0 + jy;
+            const float dy2 = (row - q.Y) * (row - q.Y);
+            unsigned bits = 0;
+#pragma unroll
+            for (int jx = 0; jx < kSplatSlots; jx++) bits |= (dx2[jx] + dy2 <= rad2_max) ? 1u << jx : 0u;
+            bits = (jy < nh && row >= 0 && row <= H - 1) ? bits & col_ok : 0u;
+            pattern |= (unsigned long long)bits << (8 * jy);
+        }
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    // ---- every lane is now a pixel of an 8x8 tile of the wave's window
+    // ---- every lane is now BOTH a ray (what it parked) and a pixel of an 8x8 tile of the wave's window: lane l <-> pixel
+    // (tc + (l & 7), tr + (l >> 3)).  Per tile, first as a ray: the lane moves its pattern to tile coordinates -- a 64-bit
+    // shift by 8 dy + dx, (dx, dy) its window's origin relative to the tile, columns that would wrap into a neighbouring row
+    // masked off first -- which makes it THE LANE MASK of the pixels this ray renders in this tile, and works out where in its
+    // parked factors pixel (0, 0) of the tile would sit.  Then as a pixel: a wave-uniform loop over the rays with a non-empty
+    // mask reads ray r's mask and offsets out of lane r's registers (v_readlane -> scalar registers), and under that mask the
+    // vector unit multiplies the two factors, rounds the increment to f32 like the reference (.cu:1519-1528: float inc,
+    // atomicAdd(float)) and adds it: 2 LDS reads + 6 vector instructions per ray and tile where the per-pixel form of rounds
+    // 2-4 (unpack, clamp, radius test, selects) took ~25.
+    const int lx = lane & 7, ly = lane >> 3;
+    const unsigned f_base = (unsigned)(size_t)&lds.f[0][0];              // LDS byte address of the parked factors
+    const unsigned px_addr = f_base + 8u * (unsigned)lx, py_addr = f_base + 8u * (unsigned)(kSplatSlots + ly);
     int taps = 0;
     for (int ty = 0; ty < tiles_y; ty++)
         for (int tx = 0; tx < tiles_x; tx++) {
             const int tc = cmin + 8 * tx, tr = rmin + 8 * ty;           // tile origin (wave-uniform)
-            const bool touch = q.valid && q.c0 <= tc + 7 && q.c1 >= tc && q.r0 <= tr + 7 && q.r1 >= tr;
-            unsigned long long rays = ballot(touch);                  // rays whose window meets this tile
+            // as a ray
+            const int dx = q.c0 - tc, dy = q.r0 - tr;                   // in [-6, 7] for a window that meets the tile
+            const bool touch = q.valid && dx <= 7 && dx >= -(kSplatSlots - 1) && dy <= 7 && dy >= -(kSplatSlots - 1);
+            const int lo = dx < 0 ? -dx : 0, hi = dx > 0 ? 7 - dx : 7;  // columns jx of the pattern with 0 <= jx + dx <= 7
+            const unsigned row_bits = (0xffu >> (7 - hi)) & (0xffu << lo) & 0xffu;
+            const unsigned cols = row_bits * 0x01010101u;
+            const unsigned long long kept = pattern & (((unsigned long long)cols << 32) | cols);
+            const int sh = dy * 8 + dx;                                 // in [-54, 63]: rows that leave the tile drop out of the word
+            const unsigned long long mine = touch ? (sh >= 0 ? kept << sh : kept >> -sh) : 0ull;
+            const int m_lo = (int)(unsigned)mine, m_hi = (int)(unsigned)(mine >> 32);
+            taps += __popcll(mine);
+            unsigned long long rays = ballot(mine != 0);                // rays that render something in this tile
             if (rays == 0) continue;
-            const int col = tc + (lane & 7), row = tr + (lane >> 3);
-            const bool in_image = col >= 0 && col <= W - 1 && row >= 0 && row <= H - 1;
+            // as a pixel
             double sum = 0.0;
-            // wave-uniform loop over the parked rays, branch-free inside (the factor reads use clamped slots, so they
-            // issue before the tests resolve and consecutive rays overlap)
-            const int r_lo = __ffsll((long long)rays) - 1, r_hi = 63 - __clzll((long long)rays);
-#pragma unroll 2
-            for (int r = r_lo; r <= r_hi; r++) {
-                if (!((rays >> r) & 1ull)) continue;                    // wave-uniform
-                const float4 h = lds.head[r];                           // broadcast read
-                const int packed = __float_as_int(h.w);
-                const int jx = col - __float_as_int(h.z), jy = row - ((packed << 12) >> 12);       // r0: sign-extended 20 bits
-                const double fx = lds.f[r][min((unsigned)jx, (unsigned)(kSplatSlots - 1))];
-                const double fy = lds.f[r][kSplatSlots + min((unsigned)jy, (unsigned)(kSplatSlots - 1))];
-                const float rad2 = (col - h.x) * (col - h.x) + (row - h.y) * (row - h.y);         // sqrtf(rad2) <= rfD  <=>  rad2 <= rad2_max
-                const bool render = in_image && (unsigned)jx < (unsigned)((packed >> 20) & 0xf) && (unsigned)jy < (unsigned)((packed >> 24) & 0xf) &&
-                                    rad2 <= rad2_max;
-                const float inc = (float)(fx * fy);
-                sum += render ? (double)inc : 0.0;
-                taps += render ? 1 : 0;
+            const int first = __ffsll((long long)rays) - 1;
+            const int dx0 = __builtin_amdgcn_readlane(dx, first), dy0 = __builtin_amdgcn_readlane(dy, first);
+            if (ballot(mine != 0 && (dx != dx0 || dy != dy0)) == 0) {       // wave-uniform
+                // EVERY ray that renders here has the same window (one light source per wave: seven BOS waves in eight): the
+                // factors of ray r sit at a compile-time offset from one per-lane address -- the loop over r is unrolled, no
+                // offset travels through v_readlane, no address is formed per ray: 2 v_readlane + 2 LDS reads + 4 f64
+                // instructions per ray.
+                const unsigned ax = px_addr - 8u * (unsigned)dx0, ay = py_addr - 8u * (unsigned)dy0;
+#pragma unroll
+                for (int r = 0; r < 64; r++) {
+                    const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(m_hi, r) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readlane(m_lo, r);
+                    if (lane_of_mask(m)) {
+                        const double fx = *reinterpret_cast<const __attribute__((address_space(3))) double *>(ax + r * kSplatStride);
+                        const double fy = *reinterpret_cast<const __attribute__((address_space(3))) double *>(ay + r * kSplatStride);
+                        const float inc = (float)(fx * fy);
+                        sum += (double)inc;
+                    }
+                }
+            } else {
+                // windows differ (a wave across two sources, a cone across a pixel boundary): ray r's offsets travel with its
+                // mask (both in one word: they fit 16 bits each)
+                const int offs = ((lane * (int)kSplatStride - 8 * dx) & 0xffff) | ((lane * (int)kSplatStride - 8 * dy) << 16);
+                while (rays != 0) {
+                    const int r = __ffsll((long long)rays) - 1;
+                    rays &= rays - 1;
+                    const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(m_hi, r) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readlane(m_lo, r);
+                    const int o = __builtin_amdgcn_readlane(offs, r);
+                    const unsigned ax = px_addr + (unsigned)(int)(short)(o & 0xffff), ay = py_addr + (unsigned)(o >> 16);
+                    if (lane_of_mask(m)) {
+                        const double fx = *reinterpret_cast<const __attribute__((address_space(3))) double *>(ax);
+                        const double fy = *reinterpret_cast<const __attribute__((address_space(3))) double *>(ay);
+                        const float inc = (float)(fx * fy);
+                        sum += (double)inc;
+                    }
+                }
             }
-            if (sum != 0.0) atomicAdd(&image[(size_t)row * W + col], sum);
+            if (sum != 0.0) atomicAdd(&image[(size_t)(tr + ly) * W + (tc + lx)], sum);      // pixels outside the image never receive anything
         }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();                                    // the area may be re-parked by the caller's next use

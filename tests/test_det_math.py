@@ -68,3 +68,42 @@ def test_philox_normals_are_standard_normal_and_keyed(oracle):
     z = oracle.normal2(seed=0, n=1, draw=0, stream=0)[0]
     r = np.sqrt(-2 * np.log(u1))
     assert np.allclose(z, [r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)], rtol=1e-6)
+
+
+def test_det_erf_absolute_error_bound(oracle):
+    """photon_det_erf (the Gaussian-spot splat's erf, shared by oracle and product since round 5): |error| <= 4e-16 for
+    every argument, against 50-digit values -- on a dense random set over [-6.5, 6.5], the interval seams k / 16 and their
+    neighbours, the splat's own arguments sqrt(8) (j +- 1/2 - frac) / D, and the special values."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    rng = np.random.default_rng(5)
+    seams = np.arange(0, 97) / 16.0
+    x = np.concatenate([rng.uniform(-6.5, 6.5, 60_000), seams, np.nextafter(seams, 0), np.nextafter(seams, 10), -seams,
+                        (np.sqrt(np.float32(8.0)).astype(np.float64) * (np.arange(-4, 5)[None, :] + 0.5 - rng.random((2000, 1))) / 3.0).ravel(),
+                        rng.uniform(-1e-3, 1e-3, 2000)])
+    y = oracle.det_erf(x)
+    want = np.array([float(mp.erf(mp.mpf(float(v)))) for v in x])          # correctly rounded reference values
+    exact_err = np.array([abs(float(mp.mpf(float(a)) - mp.erf(mp.mpf(float(v))))) for a, v in zip(y[:5000], x[:5000])])
+    assert np.abs(y - want).max() <= 4e-16 and exact_err.max() <= 4e-16, (np.abs(y - want).max(), exact_err.max())
+    nz = x != 0
+    assert np.array_equal(oracle.det_erf(-x[nz]), -y[nz])                   # odd, exactly (at 0 itself: -6.9e-18, within the bound)
+    s = oracle.det_erf(np.array([6.0, 7.5, 1e300, np.inf, -6.0, -np.inf, 0.0, np.nan]))
+    assert np.array_equal(s[:6], [1, 1, 1, 1, -1, -1]) and abs(s[6]) <= 1e-16 and np.isnan(s[7])
+    # against glibc's erf: the two agree to a few 1e-16 (what test_erf_form_sensitivity sees on images)
+    from scipy.special import erf as sp_erf
+    assert np.abs(y - sp_erf(x)).max() <= 6e-16
+
+
+def test_div_rcp_equals_division(oracle):
+    """photon_det_div_rcp(a, b, 1 / b) -- the product's erf splat divides its sixteen erf arguments per ray by the spot
+    diameter this way -- is the correctly rounded a / b the oracle (and the reference) compute with a division: no
+    mismatch on 8e6 quotients, divisors = the float spot diameters a camera can have (3 px in every shipped case)."""
+    rng = np.random.default_rng(9)
+    divisors = [3.0, 1.0, 2.5, 0.75, 7.3, 1.9999998807907104, 1e-3, 37.0] + [float(np.float32(v)) for v in rng.uniform(0.5, 20.0, 8)]
+    for b in divisors:
+        a = np.concatenate([rng.uniform(-15.0, 15.0, 400_000) * b / 3.0, rng.standard_normal(100_000) * 1e-3])
+        # the splat's own numerators: (double)sqrtf(8) * ((double)(float)(idx - X) -+ 0.5)
+        X = rng.uniform(8.0, 1016.0, 50_000).astype(np.float32)
+        idx = (np.floor(X) + rng.integers(-4, 5, X.size)).astype(np.float32)
+        a = np.concatenate([a, float(np.sqrt(np.float32(8.0))) * ((idx - X).astype(np.float64) - 0.5)])
+        assert oracle.det_div_rcp_mismatches(a, b) == 0, b

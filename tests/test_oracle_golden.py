@@ -671,3 +671,30 @@ def test_bspline_weight_form_sensitivity(oracle, tmp_path):
     print("B-spline weight form sensitivity:", {k: f"{v:.2e}" for k, v in measured.items()})
     for name in ("c3_slice_rk4", "c3_slice_euler", "v48_rk4"):
         assert measured[name] < 1e-6, (name, measured[name])
+
+
+def test_erf_form_sensitivity(oracle):
+    """Round 5 moved the Gaussian-spot splat's erf(double) -- four per rendered pixel (parallel_ray_tracing.cu:1504-1528) --
+    from "whatever erf the platform has" (glibc's in the oracle, ocml's in the product; CUDA's in the reference) to ONE
+    table-driven polynomial both sides share, photon_det_erf (include/photon_det_math.h, |error| <= 4e-16:
+    tests/test_det_math.py).  An oracle edit that accompanies a kernel edit on an unpinned row is BOUNDED (DESIGN.md section
+    5): the `libm_erf` build of the same oracle source (glibc's erf) against the shipped one on the erf-splat image cases.
+    The increments are rounded to f32 before they are accumulated, and both functions are within an ulp of erf: measured,
+    the images are BIT-IDENTICAL (0.0 on the two sample BOS images, on a small synthetic case, and on a 5e6-ray case = 1e8
+    increments run by hand); asserted < 1e-7 relative L2 so that a different glibc does not turn the test red."""
+    from oracle_lib import Oracle
+    libm = Oracle(libm_erf=True)
+
+    def rel(x, y):
+        x, y = x.astype(np.float64), y.astype(np.float64)
+        return np.linalg.norm(x - y) / np.linalg.norm(x)
+
+    measured = {}
+    for name in ("bos_im1", "bos_im2"):
+        call = load_fixture_call(name)
+        measured[name] = rel(oracle.render(call)[0], libm.render(call)[0])
+    call = scenes.bos_scene(n_dots=12, points_per_dot=40, rays_per_source=200, seed=5)
+    measured["bos_small"] = rel(oracle.render(call)[0], libm.render(call)[0])
+    print("erf form sensitivity (rel L2):", {k: f"{v:.2e}" for k, v in measured.items()})
+    for name, v in measured.items():
+        assert v < 1e-7, (name, v)
