@@ -475,6 +475,12 @@ __device__ __forceinline__ float sqrt_threshold(float r) {
 }
 
 __device__ __forceinline__ bool lane_of_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// (bits << 1) | (a <= b) in two instructions: the comparison into VCC, then bits + bits + carry-in (the compiler's own form
+// of "or in a bit where the test holds" is a compare, a select and an or)
+__device__ __forceinline__ unsigned shift_in_le(unsigned bits, float a, float b) {
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+    return bits;
+}
 
 // Must be called by all 64 lanes of the wave.  Returns this lane's share of the number of rendered pixels (the wave's
 // total is what the callers accumulate).
@@ -555,7 +561,7 @@ __device__ __forceinline__ int erf_splat_wave(double *image, int W, int H, const
             const float dy2 = (row - q.Y) * (row - q.Y);
             unsigned bits = 0;
 #pragma unroll
-            for (int jx = 0; jx < kSplatSlots; jx++) bits |= (dx2[jx] + dy2 <= rad2_max) ? 1u << jx : 0u;
+            for (int jx = kSplatSlots - 1; jx >= 0; jx--) bits = shift_in_le(bits, dx2[jx] + dy2, rad2_max);      // bit jx <- pixel (jx, jy)
             bits = (jy < nh && row >= 0 && row <= H - 1) ? bits & col_ok : 0u;
             pattern |= (unsigned long long)bits << (8 * jy);
         }

@@ -75,7 +75,11 @@ constexpr int kBrickSlab = 8 * kBrickPitch;                     // texels betwee
 constexpr int kCubicTileLayers = PHOTON_CUBIC_TILE_LAYERS;
 static_assert(kCubicTileLayers >= 4 && kCubicTileLayers <= 8, "PHOTON_CUBIC_TILE_LAYERS");
 template <int INTERP> constexpr int tile_texels() { return INTERP == 2 ? 16 * kCubicTileLayers : PHOTON_LINEAR_TILES * PHOTON_LINEAR_TILE_LAYERS * 4; }
-template <int INTERP> constexpr int wave_lds_texels() { return tile_texels<INTERP>() + (INTERP == 2 ? 4 : 2) * kBrickSlab; }
+#ifndef PHOTON_SPINS_IN_LDS
+#define PHOTON_SPINS_IN_LDS 1       // the RK4 trilinear march keeps its rays' `continue` counters in LDS (touched on a rare path only)
+#endif
+constexpr int kSpinSlotTexels = PHOTON_SPINS_IN_LDS ? 32 : 0;               // 64 lanes x 2 x 4 bytes behind the trilinear brick
+template <int INTERP> constexpr int wave_lds_texels() { return tile_texels<INTERP>() + (INTERP == 2 ? 4 : 2) * kBrickSlab + (INTERP == 1 ? kSpinSlotTexels : 0); }
 constexpr int kWaveLdsTexels = wave_lds_texels<2>();
 
 // 64-tap sum (slab order) over the block parked in LDS: blk[c*16 + b*4 + a] = texel (a,b,c); each texel
@@ -775,7 +779,13 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
                                                        const f4 *__restrict__ tex, f4 *blk, f3 scale, CNT &mc,
                                                        const InterDump &idump, MarchResume &rs) {
     const MarchU u = make_march_consts(v, scale);
-    int loop_ctr = rs.loop_ctr, spins = rs.spins;
+    int loop_ctr = rs.loop_ctr;
+    constexpr bool kSpinLds = PHOTON_SPINS_IN_LDS && INTERP == 1;
+    int spins = rs.spins;
+    int *const spin_slot = reinterpret_cast<int *>(blk + tile_texels<1>() + 2 * kBrickSlab) + (threadIdx.x & 63);
+    if (kSpinLds) *spin_slot = spins;
+    int *const ctr_slot = spin_slot + 64;
+    if (kSpinLds) *ctr_slot = loop_ctr;
     unsigned trips = rs.trips_base;                             // wave-uniform; no lane's loop_ctr exceeds it
     const unsigned trips_end = rs.max_trips == ~0u ? ~0u : trips + rs.max_trips;
     Parked parked = parked_none();
@@ -792,9 +802,9 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         f3 lookup = lookup_index_u(rpos, u);
         const unsigned long long in_a = inside_mask(rpos, u);
         unsigned long long not_over = ~0ull;
-        if (trips > (unsigned)kLoopMax) not_over = ~ballot(loop_ctr > kLoopMax);       // wave-uniform; a safety cap, never reached
+        if (trips > (unsigned)kLoopMax) not_over = ~ballot((kSpinLds ? *ctr_slot : loop_ctr) > kLoopMax);       // wave-uniform; a safety cap, never reached
         trips++;
-        if (SAVE && INTERP == 1) { if (lane_of(active & not_over)) record_intermediate(idump, loop_ctr, rpos, rdir); }
+        if (SAVE && INTERP == 1) { if (lane_of(active & not_over)) record_intermediate(idump, kSpinLds ? *ctr_slot : loop_ctr, rpos, rdir); }
         const unsigned long long alive = active & not_over & (in_a | first);           // else the reference's `break`
         unsigned long long go = alive, spin = 0;                // go: lane samples A and -- if that succeeds -- B and C
         if ((alive & ~in_a) != 0) {                             // wave-uniform: rays that start outside the box (.h:1043-1049)
@@ -813,11 +823,11 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         if (spin != 0) {                                        // wave-uniform, rare
             if (lane_of(spin)) {
                 rpos = rpos + u.spin_step * rdir;
-                spins++;
+                if (kSpinLds) { spins = *spin_slot + 1; *spin_slot = spins; } else spins++;
             }
             active &= ~(spin & ballot(spins > kSpinMax));
         }
-        loop_ctr += lane_of(go) ? 1 : 0;
+        if (kSpinLds) { if (lane_of(go)) atomicAdd(ctr_slot, 1); } else loop_ctr += lane_of(go) ? 1 : 0;
         const float n_a = val.w + 1;
         const float delta_t = u.step / n_a;
         f3 T_n = n_a * rdir;
@@ -851,7 +861,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         count_iterations(mc, go);
         if (INTERP == 1 && spin != 0) { if (lane_of(spin)) prev.set(f4{0, 0, 0, 0}); }
     }
-    rs.loop_ctr = loop_ctr; rs.spins = spins;
+    rs.loop_ctr = kSpinLds ? *ctr_slot : loop_ctr; rs.spins = kSpinLds ? *spin_slot : spins;
     if (INTERP == 1) rs.val_prev = prev.get();
     return active;
 }

@@ -89,6 +89,7 @@ constexpr unsigned kQueueStride = 16;                           // u32 per queue
 #endif
 constexpr unsigned kSubQueues = PHOTON_SUBQUEUES;
 constexpr unsigned kQueues = 64;                                // room for 8 XCDs x 8 sub-queues
+constexpr unsigned kQueueDoneSlot = 63;                         // the line that counts the waves that have left (march_kernel re-arms the queues itself)
 // Consecutive 64-ray groups an XCD's queue owns as one CHUNK: 2^shift.  Large chunks keep the rays of neighbouring sources
 // in one L2; small ones balance the XCDs' queues at the end of a launch.  Measured on C3 with the segmented march (HBM
 // traffic does not care: 4.0-4.15 GB): tricubic RK4 march with chunks of 128 / 32 / 16 / 8 groups 57.70 / 57.59 / 57.53 /

@@ -165,6 +165,7 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
     InterDump idump{nullptr, nullptr, 0, 0, 0u};
     if (SAVE) idump = load_arg(&a->idump);
     idump.ray = r;                                              // chunk-global ray id, like the final dumps
+    const unsigned long long marching_mask = ballot(marching);  // scalar from here on
     unsigned long long still;                                   // lanes whose rays are still in the volume when the segment ends
     if (INTERP == 1 && vol.weight_scale > 0.f)                  // kernel-uniform: the texture unit's 8-bit weights (the default) / exact f32
         still = trace_volume_coop<ALGO, INTERP, SAVE, NOISE, true, WaveCount>(marching, p, d, vol, tex, tile, tot.mc, gn, idump, rs);   // all 64 lanes
@@ -174,7 +175,13 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
         MarchArgsPtr b = march_args();
         const RayStateDev st = load_arg(&b->st);                // loaded again: not carried through the march in SGPRs
         const bool fresh = !SEG || seg == 0, last = !SEG || seg + 1u >= b->segments;      // likewise
-        const unsigned group = (unsigned)__builtin_amdgcn_readfirstlane((int)r) >> 6;
+        // the ray's index and predicates are formed again from the (scalar) group number rather than carried through the march
+        // loop in vector registers the loop has no room for
+        unsigned g2 = group;
+        asm volatile("" : "+s"(g2));
+        const unsigned r = g2 * 64u + (threadIdx.x & 63u);
+        const bool has_ray = r < b->n_rays;
+        const bool marching = lane_of(marching_mask);
         if (last) {
             if (marching) {
                 st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
@@ -260,6 +267,14 @@ __global__ __launch_bounds__(PHOTON_MARCH_BLOCK, (march_waves<ALGO, INTERP, NOIS
         }
     }
     if (lane == 0) {
+        // The launch's last wave re-arms the work queues for the next launch (no memset between launches: at one GPU's eighth
+        // of the trilinear job every tiny launch is 0.2 % of the step).  A wave takes its ticket after its last queue access
+        // -- whose returned value it has consumed -- so the wave that draws the last ticket finds every counter final.
+        unsigned *q = march_args()->queue;
+        if (atomicAdd(&q[kQueueDoneSlot * kQueueStride], 1u) == gridDim.x * (PHOTON_MARCH_BLOCK / 64u) - 1u) {
+            for (unsigned k = 0; k < 8u * kSubQueues; k++) q[k * kQueueStride] = 0u;
+            q[kQueueDoneSlot * kQueueStride] = 0u;
+        }
         unsigned long long *slot = counter_slot(march_args()->counters);
         if (tot.mc.iterations) atomicAdd(&slot[CNT_ITER], (unsigned long long)tot.mc.iterations);
         if (tot.mc.samples) atomicAdd(&slot[CNT_SAMPLES], (unsigned long long)tot.mc.samples);

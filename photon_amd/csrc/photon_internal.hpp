@@ -95,13 +95,15 @@ struct photon_scene {
     size_t ws_rays = 0;
     unsigned long long *d_counters = nullptr;   // kCounterSlots x kCounterStride statistics words; the last word of slot 0 is the march's
                                         // hand-off error count (scene_error_word), so whatever zeroes the statistics zeroes it too
-    unsigned *d_queue = nullptr;        // the march's work queues: room for 64 counters a cache line apart, 8 XCDs x kSubQueues (4) in use
+    unsigned *d_queue = nullptr;        // the march's work queues: room for 64 counters a cache line apart, 8 XCDs x kSubQueues (4) in use + the
+                                        // ticket of the waves that have left; zeroed at creation, re-armed by every launch's last wave
     int num_cus = 256;                  // compute units of the scene's device (size of the persistent march grid)
     unsigned march_epoch = 0;           // tag of the last segmented march launch in ws.seg_flag
     int march_segments = -1;            // photon_scene_set_march_segments: -1 the library's choice, 1 whole marches, n segments
     unsigned long long *d_profile = nullptr;    // wave-timing slots of the march launches (photon_scene_set_march_profile), or nullptr
     unsigned prof_next = 0;             // march launches since the slots were last zeroed
     double *d_acc = nullptr;            // f64 sensor accumulator, W*H
+    bool acc_clean = false;             // the accumulator is all zeros (finalize_image_kernel leaves it so): the next trace needs no memset
     bool launched = false;              // kernels of this scene may be in flight: its blocks go back to the cache only after a device sync
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // statistics window (photon_scene_stats_begin / _end): traces inside it record their events and leave the counters

@@ -202,8 +202,6 @@ int launch_march(photon_scene *s, const photon_volume *vol, int algorithm, unsig
     const unsigned all_blocks = (n + PHOTON_MARCH_BLOCK - 1) / PHOTON_MARCH_BLOCK;
     const unsigned fill_blocks = (unsigned)s->num_cus * 8u * (256 / PHOTON_MARCH_BLOCK);
     const dim3 mblock(PHOTON_MARCH_BLOCK), mgrid(std::min(all_blocks, fill_blocks));
-    if (algorithm == 1 || algorithm == 2)
-        PH_CHECK(hipMemsetAsync(s->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned), stream));
     if (ev_march_begin) PH_CHECK(hipEventRecord(ev_march_begin, stream));
     unsigned long long *profile = nullptr;                  // wave timing of this launch, while there are free slots
     if (s->d_profile && s->prof_next < kProfileLaunches && (algorithm == 1 || algorithm == 2))
@@ -284,6 +282,7 @@ extern "C" int photon_trace_volume_rays_queued(const photon_volume_t *vol, int r
         PH_CHECK(pool_malloc((void **)&sc.d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
         PH_CHECK(hipMemset(sc.d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
         PH_CHECK(pool_malloc((void **)&sc.d_queue, kQueues * kQueueStride * sizeof(unsigned)));
+        PH_CHECK(hipMemset(sc.d_queue, 0, kQueues * kQueueStride * sizeof(unsigned)));      // zero once: every march launch leaves them zero
         { const int rc = ensure_workspace(&sc, (size_t)n); if (rc) return rc; }
         std::vector<float> soa((size_t)n * 6);
         for (int i = 0; i < n; i++)

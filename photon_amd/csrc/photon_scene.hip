@@ -421,6 +421,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     e = pool_malloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     e = pool_malloc((void **)&s->d_queue, kQueues * kQueueStride * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(s->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned));     // zero once: every march launch leaves them zero
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     {
         int dev = 0, cus = 0;

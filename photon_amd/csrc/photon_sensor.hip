@@ -145,10 +145,13 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void splat_kernel(unsigne
 
 // image_array is read-modify-write (parallel_ray_tracing.cu:3309,3675): fold the f64 accumulator of
 // this call into the caller's f32 image, one rounding per pixel.
-__global__ __launch_bounds__(256) void finalize_image_kernel(float *__restrict__ image, const double *__restrict__ acc,
-                                                             size_t n) {
+// The accumulator is left zeroed for the next trace of the scene (one launch fewer per trace than a memset would be).
+__global__ __launch_bounds__(256) void finalize_image_kernel(float *__restrict__ image, double *__restrict__ acc, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) image[i] = (float)((double)image[i] + acc[i]);
+    if (i < n) {
+        image[i] = (float)((double)image[i] + acc[i]);
+        acc[i] = 0.0;
+    }
 }
 
 namespace photon {
@@ -187,6 +190,7 @@ int launch_finalize(photon_scene *s, float *d_image, hipStream_t stream) {
     const size_t npix = (size_t)s->dev.cam.x_pixel_number * s->dev.cam.y_pixel_number;
     hipLaunchKernelGGL(finalize_image_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, d_image, s->d_acc, npix);
     PH_CHECK(hipGetLastError());
+    s->acc_clean = true;
     return 0;
 }
 

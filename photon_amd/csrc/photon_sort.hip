@@ -59,7 +59,13 @@ __global__ __launch_bounds__(256) void morton_keys_kernel(const float *__restric
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x0 = dec(box[0]), x1 = dec(box[1]), y0 = dec(box[2]), y1 = dec(box[3]);
-    const double fx = x1 > x0 ? 65535.0 / ((double)x1 - x0) : 0.0, fy = y1 > y0 ? 65535.0 / ((double)y1 - y0) : 0.0;
+    // ONE scale for both axes (the longer side of the box spans the 2^16 cells): the Z-order's cells are squares in the
+    // sources' own units whatever the shape of the launched range.  Scaled per axis -- round 3's form -- a range that is a
+    // strip of the field (one GPU's shard of a tile-sorted particle list: 60 mm x 7.5 mm) got cells eight times longer than
+    // high, its waves' 64 neighbouring sources spanned patches eight times wider, and the eighth of C5 marched at 64 % of the
+    // whole job's rate per ray.
+    const double ext = fmax((double)x1 - x0, (double)y1 - y0);
+    const double fx = ext > 0.0 ? 65535.0 / ext : 0.0, fy = fx;
     const double qx = ((double)x[i] - x0) * fx, qy = ((double)y[i] - y0) * fy;
     const unsigned ix = qx == qx ? (unsigned)qx : 0u, iy = qy == qy ? (unsigned)qy : 0u;    // NaN -> 0
     keys[i] = spread16(ix & 0xffffu) | (spread16(iy & 0xffffu) << 1);

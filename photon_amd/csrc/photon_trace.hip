@@ -103,7 +103,8 @@ namespace photon {
 
 int begin_accumulate(photon_scene *s, hipStream_t stream) {
     const size_t npix = (size_t)s->dev.cam.x_pixel_number * s->dev.cam.y_pixel_number;
-    PH_CHECK(hipMemsetAsync(s->d_acc, 0, npix * sizeof(double), stream));
+    if (!s->acc_clean) PH_CHECK(hipMemsetAsync(s->d_acc, 0, npix * sizeof(double), stream));      // else: left zeroed by the last finalize
+    s->acc_clean = false;
     return 0;
 }
 
