@@ -145,8 +145,8 @@ struct CallArgs {
 // chunk loop over light-field sources (parallel_ray_tracing.cu:3505-3558): the sources are cut into contiguous,
 // count-balanced blocks, one per listed device; each device's host thread uploads ONLY its block (plus the replicated
 // tables, optics and volume -- the NRRD is parsed once, SharedDensity) and renders into its scene's private f64
-// accumulator on a stream of its own, while the calling thread uploads the caller's image to the first device and settles
-// peer access (once per pair and process).  When the workers are done ONE kernel on the first device sums the
+// accumulator on a stream of its own, while the calling thread uploads the caller's image to the first device (peer access
+// from the first device to the others has been settled before: once per pair and process).  When the workers are done ONE kernel on the first device sums the
 // accumulators through their peer-mapped pointers and folds the sum into the image (gather_sum_kernel).  A device the
 // first one cannot map (no xGMI / PCIe peer path) has its accumulator copied into a block of the cache first
 // (hipMemcpyPeerAsync, all such copies in flight together) -- said on stderr when the pair is first seen, and per call
@@ -164,6 +164,13 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
     SharedDensity shared;
     std::vector<std::thread> workers;
     const auto t_start = std::chrono::steady_clock::now();
+    // peer access from the first device to the others, BEFORE any worker allocates its accumulator: what the sum's kernel
+    // dereferences must have been allocated under the mapping (photon_pool.hpp); once per pair and process, then a table look-up
+    // PHOTON_PEER_READS=0: never dereference another device's memory, always stage (for a node whose peer mappings misbehave)
+    const char *pr = getenv("PHOTON_PEER_READS");
+    const bool allow_direct = !(pr && strcmp(pr, "0") == 0);
+    std::vector<char> direct(K, 1);
+    for (size_t k = 1; k < K; k++) direct[k] = devices[k] == devices[0] || (allow_direct && peer_access(devices[0], devices[k])) ? 1 : 0;
     for (size_t k = 0; k < K; k++) {
         workers.emplace_back([&, k]() {
             rcs[k] = guarded("start_ray_tracing (device worker)", [&]() -> int {
@@ -198,7 +205,7 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
             });
         });
     }
-    // meanwhile, on the calling thread: peer access from the first device to the others, the caller's image onto the first device
+    // meanwhile, on the calling thread: the caller's image onto the first device
     int rc = 0;
     auto check = [&](hipError_t err, int line) {
         if (err != hipSuccess && !rc) {
@@ -207,8 +214,6 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
         }
         return rc == 0;
     };
-    std::vector<char> direct(K, 1);
-    for (size_t k = 1; k < K; k++) direct[k] = peer_access(devices[0], devices[k]) ? 1 : 0;
     PoolBuffer<float> d_img;
     if (check(hipSetDevice(devices[0]), __LINE__) && check(d_img.alloc(npix), __LINE__))
         check(hipMemcpy(d_img.p, image_array, npix * sizeof(float), hipMemcpyHostToDevice), __LINE__);      // .cu:3309

@@ -133,6 +133,10 @@ bool peer_access(int dev, int peer) {
         const hipError_t pe = hipDeviceEnablePeerAccess(peer, 0);
         direct = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
         if (pe != hipSuccess) (void)hipGetLastError();
+        // Kernels on `dev` will dereference pointers into `peer`'s memory.  The runtime maps what is allocated from now on;
+        // blocks idling in the cache were allocated before.  Hand them back so that whatever a scene gets from here on is a
+        // fresh allocation (once per pair and process).
+        if (direct) pool_trim(0);
         if (!direct)
             fprintf(stderr, "photon: hipDeviceEnablePeerAccess(device %d from device %d) failed: %s; its accumulators are copied through host staging\n",
                     peer, dev, hipGetErrorString(pe));

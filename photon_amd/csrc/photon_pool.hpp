@@ -44,7 +44,8 @@ struct PoolBuffer {
 // Peer access from device `dev` to the memory of device `peer`, decided ONCE per ordered pair and process
 // (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess, then remembered): true = kernels running on `dev` may dereference
 // pointers into `peer`'s memory (xGMI).  A pair that cannot is reported on stderr once, never silently.  Changes the
-// calling thread's current device to `dev`.
+// calling thread's current device to `dev`.  When a pair is enabled the block cache is emptied: call this BEFORE allocating
+// what the peer kernels will read (blocks that idled in the cache predate the mapping).
 bool peer_access(int dev, int peer);
 
 }  // namespace photon

@@ -60,3 +60,19 @@ def test_seventeen_shards_chain_the_gather(photon, oracle, workdir, monkeypatch)
     got[:8, :8] = 0.0
     rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     assert rel <= 1e-5, rel
+
+
+def test_staged_sum_when_peer_reads_are_off(photon, oracle, workdir, monkeypatch):
+    """PHOTON_PEER_READS=0: every accumulator of another DEVICE is copied to the first device before the sum (the path
+    of a pair of devices without peer access).  On this box every listed device is GPU 0, whose own accumulators are read in
+    place -- the switch must at least leave the image alone; on a multi-GPU node tools/multigpu_selfcheck.py exercises the
+    copies themselves."""
+    rho, sp, org = scenes.bos_volume(32)
+    path = scenes.write_nrrd(os.path.join(workdir, "dev32.nrrd"), rho, sp, org)
+    call = scenes.bos_scene(n_dots=9, points_per_dot=15, rays_per_source=100, density_grad_filename=path)
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    ref, _ = oracle.render(call, interpolation=2)
+    monkeypatch.setenv("PHOTON_DEVICES", "0,0,0")
+    monkeypatch.setenv("PHOTON_PEER_READS", "0")
+    got = photon.render(call).astype(np.float64)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-5

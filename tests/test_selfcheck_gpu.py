@@ -18,5 +18,5 @@ def test_multigpu_selfcheck_degenerate_on_one_gpu(photon):
     out = r.stdout.decode("utf-8", "replace")
     assert r.returncode == 0, out + r.stderr.decode("utf-8", "replace")[-1500:]
     lines = [ln for ln in out.splitlines() if ln.startswith(("PASS", "FAIL"))]
-    assert len(lines) == 3 and all(ln.startswith("PASS") for ln in lines), out
-    assert "ALL PASS" in out and "PHOTON_DEVICES=0,0" in lines[0]
+    assert len(lines) == 4 and all(ln.startswith("PASS") for ln in lines), out
+    assert "ALL PASS" in out and "PHOTON_DEVICES=0,0" in lines[0] and "PHOTON_PEER_READS=0" in lines[0] and "peer mappings" in lines[1]

@@ -9,7 +9,8 @@ sources are independent, the sensor image is a sum.  Two paths do it, and both a
 
   1. inside ONE start_ray_tracing call (PHOTON_DEVICES=all: one host thread and stream per device, shard-only uploads,
      accumulators summed by one kernel on the first device through their peer-mapped pointers): image vs the same call on
-     device 0 alone, <= 1e-5 relative L2; PHOTON_VERBOSE=1 reports, per device, the time of its shard, and per call the time
+     device 0 alone, <= 1e-5 relative L2 -- first with PHOTON_PEER_READS=0 (every accumulator copied to the first device by
+     the runtime: the conservative path), then with the peer reads; PHOTON_VERBOSE=1 reports, per device, the time of its shard, and per call the time
      of the sum and how many accumulators were read directly or went through host staging (a pair of devices without peer
      access is reported once, when it is first seen: hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess state);
   2. one process per GPU (bench.py --gpus N, RCCL sum-reduce over xGMI), strong and weak scaling, K steps, with the
@@ -50,9 +51,17 @@ def child_devices(args):
     one = lib.render(call).astype(np.float64)
     os.environ["PHOTON_DEVICES"] = args.child_devices
     os.environ["PHOTON_VERBOSE"] = "1"
+    # first with every accumulator COPIED to the first device (runtime-managed peer copies: the conservative path), then with
+    # the sum's kernel reading them through their peer mappings (the default)
+    os.environ["PHOTON_PEER_READS"] = "0"
+    staged = lib.render(call).astype(np.float64)
+    rel_staged = float(np.linalg.norm(staged - one) / np.linalg.norm(one))
+    print(json.dumps({"progress": "staged sum done", "rel_l2_staged": rel_staged}), file=sys.stderr, flush=True)
+    os.environ.pop("PHOTON_PEER_READS")
     many = lib.render(call).astype(np.float64)
     rel = float(np.linalg.norm(many - one) / np.linalg.norm(one))
-    print(json.dumps({"rel_l2": rel, "devices": args.child_devices, "rays": call.num_rays, "image_sum": float(one.sum())}), flush=True)
+    print(json.dumps({"rel_l2": rel, "rel_l2_staged": rel_staged, "devices": args.child_devices, "rays": call.num_rays,
+                      "image_sum": float(one.sum())}), flush=True)
 
 
 def run(cmd, env=None, timeout=900):
@@ -92,9 +101,13 @@ def main():
         if ln.startswith("photon:") and ("device" in ln or "devices" in ln):
             print("   ", ln)
     staged = [ln for ln in err.splitlines() if "host staging" in ln]
+    good = rc == 0 and line is not None and line["rel_l2_staged"] <= TOL
+    ok &= good
+    print(f"{'PASS' if good else 'FAIL'} start_ray_tracing with PHOTON_DEVICES={devices}, accumulators copied to the first device (PHOTON_PEER_READS=0): "
+          + (f"rel L2 vs one device {line['rel_l2_staged']:.2e} (<= {TOL:g})" if line else f"no result (rc {rc}): {err[-400:]}"))
     good = rc == 0 and line is not None and line["rel_l2"] <= TOL
     ok &= good
-    print(f"{'PASS' if good else 'FAIL'} start_ray_tracing with PHOTON_DEVICES={devices}: "
+    print(f"{'PASS' if good else 'FAIL'} start_ray_tracing with PHOTON_DEVICES={devices}, accumulators read through peer mappings: "
           + (f"rel L2 vs one device {line['rel_l2']:.2e} (<= {TOL:g}), {line['rays']} rays" if line else f"no result (rc {rc}): {err[-400:]}"))
     if n > 1:
         good = not staged
