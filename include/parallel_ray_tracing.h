@@ -329,6 +329,8 @@ int photon_scene_set_skip_doomed(photon_scene_t *scene, int on);
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.
  * vol may be NULL (= simulate_density_gradients false).  stream: hipStream_t as void*
  * (NULL = default stream).  Asynchronous unless stats != NULL (stats forces a sync).
+ * The traces of ONE scene share its ray-state workspace, work queues and f64 accumulator (which every trace leaves zeroed for
+ * the next): issue them on one stream, or order them yourself when you change streams; different scenes are independent.
  * Hand-off errors of a segmented march (a wave gave up waiting for the previous piece of its group, or read a stale ray
  * state: never observed, and then the render is incomplete) are counted on the device and REPORTED where the host reads the
  * statistics -- photon_trace with stats, photon_scene_stats_end -- which zero the count when they start and fail (non-zero
