@@ -256,7 +256,8 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
     for (size_t k = 0; k < K; k++)
         if (scenes[k]) { (void)hipSetDevice(devices[k]); photon_scene_free(scenes[k]); }       // waits for the device first
     (void)hipSetDevice(devices[0]);
-    if (rc) (void)hipDeviceSynchronize();                               // a failed call may have left copies or the sum in flight                                     // the staged blocks and the image block belong to the first device's cache
+    if (rc) (void)hipDeviceSynchronize();                               // a failed call may have left copies or the sum in flight: the
+                                                                        // staged blocks and the image block go back to the cache on return
     return rc;
 }
 
