@@ -464,6 +464,12 @@ void photon_trim_caches(void);
  * <flags> = "default" or "variant[...]" with the non-default -DPHOTON_* compile-time switches of this build. */
 const char *photon_version(void);
 
+/* Self-test hook: quot[i] = a[i] / b[i], rcp[i] = 1 / b[i], root[i] = sqrt(a[i]) (host arrays of n floats) evaluated with the
+ * march loops' normal-range forms -- the compiler's correctly rounded division / square-root sequences without their range
+ * scaling (photon_amd/csrc/device_vec.hpp) -- which return the IEEE results bit for bit whenever operands and results lie
+ * within [2^-96, 2^96] in magnitude (a marching ray's sit within a few binades of 1); tests hold them against numpy. */
+int photon_selftest_normal_range_math(int n, const float *a, const float *b, float *quot, float *rcp, float *root);
+
 /* Device-to-device float4 streaming copy of `bytes` bytes, `reps` times: read + write rate in GB/s -- the HBM rate a
  * trivial kernel reaches on this GPU, which bench.py prints next to the 8 TB/s specification. */
 int photon_measure_copy_gbs(size_t bytes, int reps, double *gbs_out);

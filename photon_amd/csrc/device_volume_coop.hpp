@@ -829,7 +829,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         }
         if (kSpinLds) { if (lane_of(go)) atomicAdd(ctr_slot, 1); } else loop_ctr += lane_of(go) ? 1 : 0;
         const float n_a = val.w + 1;
-        const float delta_t = u.step / n_a;
+        const float delta_t = div_nr(u.step, n_a);              // correctly rounded, normal-range form (device_vec.hpp)
         f3 T_n = n_a * rdir;
         const f3 A = delta_t * mk3(n_a * val.x, n_a * val.y, n_a * val.z);
         f3 spos = rpos + (0.5f * delta_t) * T_n + (0.125f * delta_t) * A;       // .h:1088
@@ -856,7 +856,7 @@ __device__ __forceinline__ unsigned long long rk4_coop(bool active_lane, f3 &rpo
         if (lane_of(go)) {                                      // the iteration completed: commit
             rpos = rpos + delta_t * (T_n + (float)(1 / 6.0) * (A + 2.0f * B));         // .h:1169
             T_n = T_n + (float)(1 / 6.0) * (A + 4.0f * B + C);                         // .h:1170
-            rdir = normalize(T_n / (INTERP == 1 ? n_a : n_c));                         // .h:1178 / 1276
+            rdir = normalize_nr(div_nr(T_n, INTERP == 1 ? n_a : n_c));                 // .h:1178 / 1276
         }
         count_iterations(mc, go);
         if (INTERP == 1 && spin != 0) { if (lane_of(spin)) prev.set(f4{0, 0, 0, 0}); }
@@ -924,14 +924,14 @@ __device__ __forceinline__ unsigned long long euler_coop(bool active_lane, f3 &r
             if (lane_of(go)) {
                 const float current_n = 1 + val.w;
                 rdir = rdir + u.step * mk3(val.x, val.y, val.z);               // .h:869 (not renormalised)
-                rpos = rpos + u.step / current_n * rdir;                       // .h:875
+                rpos = rpos + div_nr(u.step, current_n) * rdir;                // .h:875
                 prev.set(val);
             }
         } else {
             if (lane_of(go)) {
-                rdir = normalize(rdir + u.step * mk3(val.x, val.y, val.z));    // .h:931-933
+                rdir = normalize_nr(rdir + u.step * mk3(val.x, val.y, val.z));   // .h:931-933
                 const float n = 1 + val.w;
-                rpos = rpos + rdir * u.step / n;                               // .h:939
+                rpos = rpos + div_nr(rdir * u.step, n);                        // .h:939
             }
         }
         loop_ctr += lane_of(go) ? 1 : 0;

@@ -149,3 +149,33 @@ extern "C" int photon_postprocess_u16(float *d_image, int width, int height, flo
     PH_CHECK(hipStreamSynchronize(stream));         // d_max dies here
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Self-test hook: the march loops' normal-range division / reciprocal / square root (device_vec.hpp: the compiler's correctly
+// rounded sequences without their range scaling) evaluated on caller-supplied operands, so that a test can hold them against
+// IEEE division and square root bit for bit (tests/test_parity_gpu.py::test_normal_range_division_and_sqrt_are_exact).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normal_range_math_kernel(int n, const float *__restrict__ a, const float *__restrict__ b,
+                                                                float *__restrict__ quot, float *__restrict__ rcp, float *__restrict__ root) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    quot[i] = div_nr(a[i], b[i]);
+    rcp[i] = rcp_nr(b[i]);
+    root[i] = sqrt_nr(a[i]);
+}
+
+extern "C" int photon_selftest_normal_range_math(int n, const float *a, const float *b, float *quot, float *rcp, float *root) {
+    if (n < 0 || !a || !b || !quot || !rcp || !root) return 1;
+    if (n == 0) return 0;
+    DeviceBuffer<float> d;
+    PH_CHECK(d.alloc((size_t)n * 5));
+    float *da = d.p, *db = d.p + n, *dq = d.p + 2 * (size_t)n, *dr = d.p + 3 * (size_t)n, *ds = d.p + 4 * (size_t)n;
+    PH_CHECK(hipMemcpy(da, a, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(db, b, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(normal_range_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, da, db, dq, dr, ds);
+    PH_CHECK(hipGetLastError());
+    PH_CHECK(hipMemcpy(quot, dq, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    PH_CHECK(hipMemcpy(rcp, dr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    PH_CHECK(hipMemcpy(root, ds, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}

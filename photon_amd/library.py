@@ -28,7 +28,7 @@ DECLARED_SYMBOLS = (
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
     "photon_scene_create_from_sources", "photon_volume_gaussian", "photon_density_gaussian_write_nrrd",
     # section 4: sensor post-processing on the device
-    "photon_postprocess_u16", "photon_measure_copy_gbs",
+    "photon_postprocess_u16", "photon_measure_copy_gbs", "photon_selftest_normal_range_math",
 )
 
 

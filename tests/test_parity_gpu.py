@@ -1240,3 +1240,56 @@ def test_nrrd_header_cannot_drive_the_allocation(photon, tmp_path):
                        "spacings: 1 1 1\nspace origin: (0,0,0)\n\n").encode() + b"\0" * 4096)
         h = ctypes.c_void_p()
         assert L.photon_volume_load_nrrd(str(p).encode(), 1, ctypes.byref(h)) != 0 and not h.value
+
+
+def test_normal_range_division_and_sqrt_are_exact(photon):
+    """The march loops divide and take square roots with the compiler's correctly rounded sequences MINUS their range scaling
+    (device_vec.hpp, div_nr / rcp_nr / sqrt_nr: 16 instructions fewer per RK4 iteration).  Same instructions on the same
+    values whenever no scaling would have happened -- so the IEEE result, bit for bit, for every operand and result within
+    [2^-96, 2^96]: held here against numpy's float32 division and square root (correctly rounded by IEEE 754) on 3e6 operand
+    pairs spread over that whole range, on the march's own neighbourhood (step / n, 1 / n, 1 / |T|), and on the specials
+    (zeros, infinities, NaN), which v_div_fixup still handles."""
+    import ctypes
+    f = photon.lib.photon_selftest_normal_range_math
+    f.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(21)
+
+    def run(a, b):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        q, r, s = (np.empty_like(a) for _ in range(3))
+        assert f(a.size, *(x.ctypes.data for x in (a, b, q, r, s))) == 0
+        return q, r, s
+
+    def bits(x):
+        return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+    # (1) the whole guaranteed range: magnitudes 2^-45 .. 2^45 each, so that quotients stay within 2^-90 .. 2^90
+    n = 1_000_000
+    a = (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-45, 46, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    b = (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-45, 46, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    q, r, s = run(a, b)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(bits(q), bits(a / b)) and np.array_equal(bits(r), bits(np.float32(1.0) / b))
+        pos = a > 0
+        assert np.array_equal(bits(s[pos]), bits(np.sqrt(a[pos]))) and np.isnan(s[~pos]).all()
+    # (2) square roots over the full guaranteed range 2^-90 .. 2^90
+    a = (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-90, 91, n)).astype(np.float32)
+    _, _, s = run(a, np.ones(n, np.float32))
+    assert np.array_equal(bits(s), bits(np.sqrt(a)))
+    # (3) where a marching ray lives: step / n and 1 / n with n = 1 + (n - 1), |T|^2 around n^2
+    nn = (1.0 + rng.uniform(-0.3, 0.3, n)).astype(np.float32)
+    step = rng.uniform(50.0, 500.0, n).astype(np.float32)
+    q, r, _ = run(step, nn)
+    assert np.array_equal(bits(q), bits(step / nn)) and np.array_equal(bits(r), bits(np.float32(1.0) / nn))
+    d2 = (nn * nn * rng.uniform(0.98, 1.02, n)).astype(np.float32)
+    _, _, s = run(d2, nn)
+    assert np.array_equal(bits(s), bits(np.sqrt(d2)))
+    # (4) specials: what v_div_fixup returns for them is what IEEE division returns
+    a = np.array([0.0, 1.0, -1.0, np.inf, 1.0, 0.0, np.nan, 1.0, np.inf, -0.0], np.float32)
+    b = np.array([1.0, 0.0, 0.0, 2.0, np.inf, 0.0, 1.0, np.nan, np.inf, 3.0], np.float32)
+    q, r, s = run(a, b)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want_q, want_r = a / b, np.float32(1.0) / b
+    for got, want in ((q, want_q), (r, want_r)):
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got[~np.isnan(want)]), bits(want[~np.isnan(want)]))
+    assert s[0] == 0.0 and s[1] == 1.0 and np.isnan(s[2]) and np.isinf(s[3])
