@@ -680,7 +680,9 @@ def main():
                              "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "flops_per_sample": flops_per_sample},
                 "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "compulsory_bytes": compulsory, "traffic": None,
                         "traffic_gbs": None, "frac": None, "algorithmic_bytes_vs_hbm_frac": round(texel_gbs / HBM_PEAK_GBS, 2)},
-                "note": "bound: instruction issue under the board's power cap.  achieved = VALU wave-instructions issued per second "
+                "note": "bound: instruction issue under the board's power cap.  frac prices the issue rate against a MEASURED yardstick at the "
+                        "MEASURED clock (below); frac_vs_nominal_issue against the nominal 2 cycles per instruction at 2.4 GHz; valu_f32.frac "
+                        "prices SURVEY 8d's algorithmic flops against the f32 vector peak.  achieved = VALU wave-instructions issued per second "
                         "(SQ_INSTS_VALU measured in this run / kernel time), peak = what the chip's 1024 SIMDs issue at the clock the march "
                         "measured for itself and the 2.17 cycles per instruction of independent FMAs; board_power says how close the "
                         "kernel runs to the cap that sets that clock.  SURVEY 8d's algorithmic bytes are texel bytes served from LDS and "
@@ -712,6 +714,11 @@ def main():
                 roofline["achieved"] = round(n_valu / kernel_s * 1e-9, 1)
                 roofline["peak"] = round(issue_peak, 1)
                 roofline["frac"] = round(roofline["achieved"] / issue_peak, 4)
+                # the same rate against the guide's NOMINAL issue rate: one wave64 VALU instruction per 2 cycles and SIMD at the
+                # 2.4 GHz maximum clock (no measured yardstick, no measured clock in the denominator)
+                nominal = SIMDS * 2.4e9 / 2.0 * 1e-9
+                roofline["frac_vs_nominal_issue"] = {"peak": round(nominal, 1), "frac": round(roofline["achieved"] / nominal, 4),
+                                                     "what": "achieved / (1024 SIMDs x 2.4 GHz / 2 cycles per instruction)"}
                 roofline["valu_issue"] = {"valu_per_wave_sample": round(n_valu / wave_samples, 1), "salu_per_wave_sample": round(n_salu / wave_samples, 1),
                                           "lds_per_wave_sample": round(n_lds / wave_samples, 2), "SQ_INSTS_VALU": n_valu,
                                           "cycles_per_inst": round(cyc, 3), "practical_cycles_per_inst": VALU_PRACTICAL_CYCLES_PER_INST,

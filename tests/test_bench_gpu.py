@@ -35,6 +35,7 @@ def test_bench_line_contract(photon):
     v = r["valu_issue"]
     assert 300 < v["valu_per_wave_sample"] < 600 and 20 < v["lds_per_wave_sample"] < 70 and v["cycles_per_inst"] > 2.0
     assert v["frac"] == pytest.approx(r["frac"], rel=2e-3)
+    assert 0 < r["frac_vs_nominal_issue"]["frac"] < r["frac"]             # the nominal yardstick (2 cycles at 2.4 GHz) is the stricter one
     assert 0 < r["lds_pipe"]["frac"] <= 1.0
     t = r["texel_rate_vs_lds"]                           # SURVEY 8d's algorithmic bytes against the LDS read roof
     assert t["unit"] == "GB/s" and 0 < t["frac"] <= 1.0 and t["frac"] == pytest.approx(t["achieved"] / t["peak"], rel=1e-3)
