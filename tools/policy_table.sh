@@ -1,8 +1,9 @@
 #!/bin/bash
 # Launch policy of the march per launch kind, with counters: march time and HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, each
-# counter in its own rocprofv3 pass) for {one-shot grid, persistent waves with 1 / 4 sub-queues per XCD} x {whole marches,
-# 8 segments} on C3 (coherent BOS cones), C5 at a quarter (incoherent, lens-major) and C4 whole (512^3: 4 GiB of texels).
-#   tools/policy_table.sh [workload ...]        variants: build/variants/lib_oneshot.so, lib_sq1.so, and the in-tree library
+# counter in its own rocprofv3 pass) for {persistent waves with 1 / 4 sub-queues per XCD} x {whole marches, 8 segments} on C3
+# (coherent BOS cones), C5 at a quarter (incoherent, lens-major) and C4 whole (512^3: 4 GiB of texels).  (Round 4's table,
+# profiles/r04_policy_table.json, also has a one-shot grid column: that code path was removed in round 5.)
+#   tools/policy_table.sh [workload ...]        variants: build/variants/lib_sq1.so (-DPHOTON_SUBQUEUES=1) and the in-tree library
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT" || exit 1
 export TMPDIR=/tmp
@@ -15,9 +16,8 @@ for w in "${wl[@]}"; do
     c4) cmd="$B --volume 512 --dots 2000" ;;
     c5) cmd="$ROOT/tools/c5_full.py 0.25" ;;
   esac
-  for v in oneshot sq1 default; do
+  for v in sq1 default; do
     for seg in 1 8; do
-      [ $v = oneshot ] && [ $seg = 8 ] && continue
       if [ $v = default ]; then unset PHOTON_LIBRARY; else export PHOTON_LIBRARY=$ROOT/build/variants/lib_$v.so; fi
       export PHOTON_MARCH_SEGMENTS=$seg
       tag=${w}_${v}_s$seg
