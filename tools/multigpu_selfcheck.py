@@ -47,10 +47,10 @@ def child_devices(args):
         scenes.write_nrrd(path, rho, sp, org)
     call = scenes.bos_scene(n_dots=args.dots, points_per_dot=100, rays_per_source=500, density_grad_filename=path)
     os.environ["PHOTON_INTERP"] = "cubic"
+    os.environ["PHOTON_VERBOSE"] = "1"                 # before the first call: the library reads it once
     os.environ.pop("PHOTON_DEVICES", None)
     one = lib.render(call).astype(np.float64)
     os.environ["PHOTON_DEVICES"] = args.child_devices
-    os.environ["PHOTON_VERBOSE"] = "1"
     # first with every accumulator COPIED to the first device (runtime-managed peer copies: the conservative path), then with
     # the sum's kernel reading them through their peer mappings (the default)
     os.environ["PHOTON_PEER_READS"] = "0"
