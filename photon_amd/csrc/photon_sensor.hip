@@ -1,6 +1,6 @@
 // photon_sensor.hip - the kernels either side of the volume march: ray generation (stage 1a) and the sensor stage
-// (stage 2: lens / aperture / apparent image, erf or 4-pixel splat into the scene's private f64 accumulator), and the
-// fold of that accumulator into the caller's image.
+// (stage 2: lens / aperture / apparent image + erf or 4-pixel splat into the scene's private f64 accumulator, one kernel),
+// and the fold of that accumulator into the caller's image.
 #include "photon_internal.hpp"
 
 using namespace photon;
@@ -32,15 +32,16 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
     st.radiance[r] = ray.radiance;
 }
 
-// Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241).  FROM_STATE=false
-// (no density gradients) generates the ray in place, so that path is one fused kernel.
-#ifndef PHOTON_SPLIT_SENSOR
-#define PHOTON_SPLIT_SENSOR 1
-#endif
+// Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241): back to the camera frame, lens / aperture /
+// apparent image, and the wave-cooperative splats (device_optics.hpp), in ONE kernel.  FROM_STATE=false (no density
+// gradients) generates the ray in place, so that path is a single kernel altogether.  (Rounds 2-4 ran the erf splat as a
+// second kernel, splat_kernel, fed through the consumed state arrays: optics and splat together wanted 94 VGPRs.  With the
+// splat's pixel loop on the scalar unit -- round 5 -- the fused kernel needs 64, and one launch and a 24 B/ray round trip
+// fewer are worth 0.12 ms per 1e7 rays: C3 trilinear 16.79 -> 16.67 ms per step, its eighth 2.285 -> 2.260, same box.)
 #ifndef PHOTON_SENSOR_WAVES
 #define PHOTON_SENSOR_WAVES 5           // the cooperative splats park 8 KiB per wave in LDS: five blocks per CU
 #endif
-template <bool FROM_STATE, bool TRAIN, bool SPLIT>
+template <bool FROM_STATE, bool TRAIN>
 __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
                                                      double *image, DumpDev dump, unsigned long long *counters) {
     __shared__ SplatLds splat_lds[4];                                   // per wave: the parked rays of the cooperative splats
@@ -106,41 +107,10 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
             dump.final_pos[3 * r] = fin.x; dump.final_pos[3 * r + 1] = fin.y; dump.final_pos[3 * r + 2] = fin.z;
         }
     }
-    if (SPLIT) {
-        // hand the erf splat to splat_kernel through the (now consumed) state arrays: the optics above and the
-        // wave-cooperative splat below each want the register file to themselves
-        if (r < n_rays) {
-            st.px[r] = req.X; st.py[r] = req.Y; st.pz[r] = req.valid ? req.D : -1.f; st.dx[r] = req.rfD;
-            st.radiance[r] = req.scale;
-        }
-    } else {
-        taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req, splat_lds[threadIdx.x >> 6]);  // all 64 lanes
-    }
+    taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req, splat_lds[threadIdx.x >> 6]);      // all 64 lanes
     taps += bilinear_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, tap, splat_lds[threadIdx.x >> 6]);     // all 64 lanes
     wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
     wave_add(&counter_slot(counters)[CNT_ON_SENSOR], (unsigned long long)on_sensor);
-}
-
-// Second half of the sensor stage for erf splats coming from the march (sensor_kernel<.., SPLIT=true>).
-__global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void splat_kernel(unsigned n_rays, RayStateDev st, double *image, int W, int H,
-                                                                         unsigned long long *counters) {
-    __shared__ SplatLds splat_lds[4];
-    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
-    SplatReq req;
-    req.valid = false;
-    req.X = req.Y = req.D = req.rfD = 0.f; req.scale = 0.0; req.c0 = req.c1 = req.r0 = req.r1 = 0;
-    if (r < n_rays) {
-        const float D = st.pz[r];
-        if (D >= 0.f) {
-            req.valid = true;
-            req.X = st.px[r]; req.Y = st.py[r]; req.D = D; req.rfD = st.dx[r];
-            req.scale = st.radiance[r];
-            req.c0 = (int)floorf(req.X - req.rfD); req.c1 = (int)ceilf(req.X + req.rfD);     // erf_splat_prepare's window
-            req.r0 = (int)floorf(req.Y - req.rfD); req.r1 = (int)ceilf(req.Y + req.rfD);
-        }
-    }
-    const int taps = erf_splat_wave(image, W, H, req, splat_lds[threadIdx.x >> 6]);     // all 64 lanes
-    wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
 }
 
 // image_array is read-modify-write (parallel_ray_tracing.cu:3309,3675): fold the f64 accumulator of
@@ -166,21 +136,11 @@ int launch_sensor(photon_scene *s, bool from_state, long long src_begin, unsigne
     const dim3 block(256), grid((n + 255) / 256);
     double *d_image = s->d_acc;
     if (from_state) {
-        // erf splats: optics and splat as two kernels (each gets the register file to itself); the 4-pixel
-        // splat is done in place by the first
-        const bool erf = PHOTON_SPLIT_SENSOR && (s->dev.cam.implement_diffraction || s->dev.elems[0].element_type == 'n');
-#define PH_SENSOR(T, S) hipLaunchKernelGGL((sensor_kernel<true, T, S>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters)
-        if (s->dev.train_mode) { if (erf) PH_SENSOR(true, true); else PH_SENSOR(true, false); }
-        else { if (erf) PH_SENSOR(false, true); else PH_SENSOR(false, false); }
-#undef PH_SENSOR
-        if (erf) {
-            PH_CHECK(hipGetLastError());
-            hipLaunchKernelGGL(splat_kernel, grid, block, 0, stream, n, s->ws, d_image, s->dev.cam.x_pixel_number,
-                               s->dev.cam.y_pixel_number, s->d_counters);
-        }
+        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<true, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        else hipLaunchKernelGGL((sensor_kernel<true, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     } else {
-        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<false, true, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
-        else hipLaunchKernelGGL((sensor_kernel<false, false, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<false, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        else hipLaunchKernelGGL((sensor_kernel<false, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     }
     PH_CHECK(hipGetLastError());
     return 0;
