@@ -220,6 +220,26 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #define PH_DS_OFF1 "16"
 #define PH_DS_OFF2 "32"
 #define PH_DS_OFF3 "48"
+// WAVE PRIORITY of the tap chains (s_setprio; 0 = the level every other instruction of the march runs at).  A SIMD holds
+// five or six waves of the march; the arbiter picks among the ready ones oldest-first, which lets a wave that is in its
+// address arithmetic or its exit tests take issue slots from one that is inside the 64-tap chain -- the chain is what
+// holds the tile's LDS rows and the wave's 80 weight registers live, so the tile turns over later.  Raising the chain
+// above the rest (3 while the DPP block of slab 0 issues, 1 for the LDS-fed slabs 1-3, 1 for the brick chain of the
+// lanes outside the tiles) cuts the busy cycles of the headline march by 12 %; the card then runs into its power limit
+// (2.26 -> 2.10 GHz on the boxes measured) and what remains is 57.1 -> 54.1 ms (C3 tricubic), 36.5 -> 35.7 ms (a
+// quarter of C5, brick chain).  The same around the eight-texel trilinear blend LOSES 1 % (16.47 -> 16.62 ms): that
+// chain is 40 instructions, the arbitration change costs more than it gives, it stays at level 0.  Levels compared on
+// one box (profiles/r05_d_priority.txt): 3/0, 2/0, 1/0 all 54.5; 3/1, 2/1 53.8-54.1; 1/1 55.2; 0/3 (only the LDS-fed
+// part raised) 58.8, worse than none.  Results do not depend on it: priority orders issue, not arithmetic.
+#ifndef PHOTON_PRIO_TAPS_DPP
+#define PHOTON_PRIO_TAPS_DPP 3
+#endif
+#ifndef PHOTON_PRIO_TAPS_LDS
+#define PHOTON_PRIO_TAPS_LDS 1
+#endif
+#ifndef PHOTON_PRIO_BRICK
+#define PHOTON_PRIO_BRICK 1
+#endif
 __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const float (&wx)[4], const float (&wy)[4],
                                                 const float (&wz)[4]) {
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -232,6 +252,9 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
     v4f t0, t1, t2, t3;
     f4 s;
     const unsigned lds = (unsigned)(size_t)blk + 64u * R;           // LDS byte address of the first row read from the tile
+#if PHOTON_PRIO_TAPS_DPP > 0
+    __builtin_amdgcn_s_setprio(PHOTON_PRIO_TAPS_DPP);
+#endif
     asm volatile(
             "ds_read_b128 %4, %28\n\t"
             "ds_read_b128 %5, %28 offset:" PH_DS_OFF1 "\n\t"
@@ -245,6 +268,9 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
               "v"(wxy[1][0]), "v"(wxy[1][1]), "v"(wxy[1][2]), "v"(wxy[1][3]), "v"(wxy[2][0]), "v"(wxy[2][1]), "v"(wxy[2][2]),
               "v"(wxy[2][3]), "v"(wxy[3][0]), "v"(wxy[3][1]), "v"(wxy[3][2]), "v"(wxy[3][3]), "v"(lds)
             : "memory");
+#if PHOTON_PRIO_TAPS_DPP != PHOTON_PRIO_TAPS_LDS
+    __builtin_amdgcn_s_setprio(PHOTON_PRIO_TAPS_LDS);
+#endif
     f4 t[4] = {f4{t0.x, t0.y, t0.z, t0.w}, f4{t1.x, t1.y, t1.z, t1.w}, f4{t2.x, t2.y, t2.z, t2.w}, f4{t3.x, t3.y, t3.z, t3.w}};
     f4 acc = f4{0, 0, 0, 0};
     acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};                 // slab 0 complete
@@ -268,6 +294,9 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
             asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
         }
     }
+#if PHOTON_PRIO_TAPS_LDS > 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return acc;
 }
 
@@ -412,7 +441,13 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
             parked.bi = ci; parked.bj = cj; parked.bk = ck;
         }
         if (in_brick) {
+#if PHOTON_PRIO_BRICK > 0
+            __builtin_amdgcn_s_setprio(PHOTON_PRIO_BRICK);
+#endif
             acc = cubic_taps_lds<kBrickPitch, kBrickSlab>(brick + (dj * kBrickPitch + di), wx, wy, wz);
+#if PHOTON_PRIO_BRICK > 0
+            __builtin_amdgcn_s_setprio(0);
+#endif
             done = true;
         }
         __builtin_amdgcn_wave_barrier();

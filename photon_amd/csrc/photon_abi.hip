@@ -381,11 +381,11 @@ static void start_ray_tracing_impl(float lens_pitch, float image_distance, scatt
         const long long kmax = (num_particles + chunk - 1) / chunk;
         rc = begin_accumulate(scene, nullptr);
         for (long long k = 0; k < kmax && rc == 0; k++) {
-            PH_VOID(hipMemset(d_fpos, 0xFF, nsave * sizeof(float)));    // all-ones = NaN (.cu:3527-3533)
-            PH_VOID(hipMemset(d_fdir, 0xFF, nsave * sizeof(float)));
+            PH_VOID(hipMemsetAsync(d_fpos, 0xFF, nsave * sizeof(float), nullptr));    // all-ones = NaN (.cu:3527-3533); the null stream, like the chunk's launches
+            PH_VOID(hipMemsetAsync(d_fdir, 0xFF, nsave * sizeof(float), nullptr));
             if (inter) {
-                PH_VOID(hipMemset(d_ipos, 0xFF, ninter * sizeof(float)));
-                PH_VOID(hipMemset(d_idir, 0xFF, ninter * sizeof(float)));
+                PH_VOID(hipMemsetAsync(d_ipos, 0xFF, ninter * sizeof(float), nullptr));
+                PH_VOID(hipMemsetAsync(d_idir, 0xFF, ninter * sizeof(float), nullptr));
             }
             const DumpDev dump{d_fpos, d_fdir, num_lightrays_save, d_ipos, d_idir, inter ? num_intermediate_positions_save : 0};
             rc = launch_chunk(scene, vol, ray_tracing_algorithm, k * chunk, std::min(num_particles, (k + 1) * chunk),

@@ -248,7 +248,7 @@ int march_error_check(photon_scene *scene) {
     if (!e) return 0;
     fprintf(stderr, "photon: %u hand-off errors between the segments of a march (a wave gave up waiting for the previous segment of its group, "
                     "or read a stale ray state): this render is not valid\n", e);
-    PH_CHECK(hipMemset(scene_error_word(scene), 0, sizeof e));
+    PH_CHECK(device_zero(scene_error_word(scene), sizeof e));
     return 1;
 }
 
@@ -280,9 +280,9 @@ extern "C" int photon_trace_volume_rays_queued(const photon_volume_t *vol, int r
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) sc.num_cus = cus;
         PH_CHECK(pool_malloc((void **)&sc.d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
-        PH_CHECK(hipMemset(sc.d_counters, 0, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
+        PH_CHECK(device_zero(sc.d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
         PH_CHECK(pool_malloc((void **)&sc.d_queue, kQueues * kQueueStride * sizeof(unsigned)));
-        PH_CHECK(hipMemset(sc.d_queue, 0, kQueues * kQueueStride * sizeof(unsigned)));      // zero once: every march launch leaves them zero
+        PH_CHECK(device_zero(sc.d_queue, kQueues * kQueueStride * sizeof(unsigned)));      // zero once: every march launch leaves them zero
         { const int rc = ensure_workspace(&sc, (size_t)n); if (rc) return rc; }
         std::vector<float> soa((size_t)n * 6);
         for (int i = 0; i < n; i++)
@@ -312,7 +312,7 @@ extern "C" int photon_scene_set_march_profile(photon_scene_t *scene, int on) {
     return guarded("photon_scene_set_march_profile", [&]() -> int {
         if (on && !scene->d_profile) {
             PH_CHECK(pool_malloc((void **)&scene->d_profile, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
-            PH_CHECK(hipMemset(scene->d_profile, 0, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
+            PH_CHECK(device_zero(scene->d_profile, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
         } else if (!on && scene->d_profile) {
             PH_CHECK(hipDeviceSynchronize());
             pool_free(scene->d_profile);

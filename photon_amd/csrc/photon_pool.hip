@@ -76,6 +76,12 @@ hipError_t device_malloc(void **out, size_t bytes) {
     return e;
 }
 
+hipError_t device_zero(void *p, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, nullptr);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 hipError_t pool_malloc(void **out, size_t bytes) {
     if (bytes == 0) bytes = 1;
     int device = 0;

@@ -89,7 +89,7 @@ extern "C" int photon_measure_copy_gbs(size_t bytes, int reps, double *gbs_out) 
     DeviceBuffer<float4> a, b;
     PH_CHECK(a.alloc(n));
     PH_CHECK(b.alloc(n));
-    PH_CHECK(hipMemset(a.p, 0, n * sizeof(float4)));
+    PH_CHECK(device_zero(a.p, n * sizeof(float4)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     PH_CHECK(hipEventCreate(&e0));
     PH_CHECK(hipEventCreate(&e1));

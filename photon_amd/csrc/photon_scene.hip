@@ -87,6 +87,14 @@ static int upload(photon_scene *s, UploadPack &pack, const T *host, size_t n, co
     *dev_out = nullptr;
     return 0;
 }
+// a zeroed region of the block (the statistics counters, the work queues): no fill kernel, no second block
+template <typename T>
+static void reserve_zeroed(UploadPack &pack, size_t n, T **dev_out) {
+    const size_t offset = (pack.host.size() + kPackAlign - 1) / kPackAlign * kPackAlign;
+    pack.host.resize(offset + n * sizeof(T));                           // std::vector value-initialises: zeros
+    pack.items.push_back({offset, reinterpret_cast<const void **>(const_cast<const T **>(dev_out))});
+    *dev_out = nullptr;
+}
 static int flush_uploads(photon_scene *s, UploadPack &pack) {
     if (pack.items.empty()) return 0;
     char *d = nullptr;
@@ -102,7 +110,7 @@ static int copy_device(photon_scene *s, const T *dev_src, size_t n, const T **de
     T *d = nullptr;
     PH_CHECK(pool_malloc((void **)&d, std::max<size_t>(n, 1) * sizeof(T)));
     s->allocs.push_back(d);
-    if (n) PH_CHECK(hipMemcpy(d, dev_src, n * sizeof(T), hipMemcpyDeviceToDevice));
+    if (n) PH_CHECK(hipMemcpyAsync(d, dev_src, n * sizeof(T), hipMemcpyDeviceToDevice, nullptr));     // the caller waits for the null stream
     *dev_out = d;
     return 0;
 }
@@ -164,9 +172,7 @@ void photon_scene_free(photon_scene_t *s) {
     pool_free(s->ws.px);
     pool_free(s->ws.radiance);
     free_resume_state(s);
-    pool_free(s->d_counters);
-    pool_free(s->d_queue);
-    pool_free(s->d_profile);
+    pool_free(s->d_profile);                                    // (d_counters and d_queue live in the upload block: allocs)
     pool_free(s->d_acc);
     for (auto &p : s->perms) pool_free(p.d_perm);
     photon_sort_scratch_free(&s->sort_scratch);
@@ -360,6 +366,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         if ((rc = copy_device<float>(s, generated->z, ns, &d.sz))) return bail(rc);
         if ((rc = copy_device<double>(s, generated->radiance, ns, &d.sradiance))) return bail(rc);
         if ((rc = copy_device<int>(s, generated->diameter_index, ns, &d.sdia))) return bail(rc);
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return bail(4);        // complete before the scene is handed out: its launches may use any stream
     } else {
         if ((rc = upload(s, pack, lsp->x, ns, &d.sx))) return bail(rc);
         if ((rc = upload(s, pack, lsp->y, ns, &d.sy))) return bail(rc);
@@ -408,6 +415,15 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         if ((rc = upload(s, pack, planes.data(), planes.size(), &d.all_planes))) return bail(rc);
         if ((rc = upload(s, pack, element_system_index, (size_t)num_elements, &d.all_sys_index))) return bail(rc);
     }
+    // The statistics counters (the march's error word among them: scene_error_word) and the work queues start at zero --
+    // every march launch leaves the queues so -- and are zeroed HERE, as part of the one host-to-device copy, which is
+    // complete when hipMemcpy returns.  hipMemset is not: it returns as soon as its fill kernel is queued on the null
+    // stream (9 us, with the fill itself 200 ms away behind a full chip: tools/ubench/null_stream_memset.hip), and a march
+    // launched on a non-blocking stream is not ordered behind the null stream -- with eight shards side by side on one device
+    // the fill of one shard's queues waited for wave slots next to that shard's own march and, once in a dozen calls, ran
+    // AFTER the march had started handing out groups (groups marched twice: images off by 6e-5, or doubled).
+    reserve_zeroed(pack, kCounterBytes / sizeof(unsigned long long), &s->d_counters);
+    reserve_zeroed(pack, (size_t)kQueues * kQueueStride, &s->d_queue);
     if ((rc = flush_uploads(s, pack))) return bail(rc);
     d.cam = *cam;
     d.noise = NoiseDev{0, 0, 0.f, 0.f, 0ull};
@@ -415,13 +431,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         fprintf(stderr, "photon: sensor needs at least one pixel\n");
         return bail(1);
     }
-    hipError_t e = pool_malloc((void **)&s->d_counters, kCounterBytes);
-    if (e == hipSuccess) e = hipMemset(s->d_counters, 0, kCounterBytes);        // the march's error word among them (scene_error_word)
-    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
-    e = pool_malloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
-    if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
-    e = pool_malloc((void **)&s->d_queue, kQueues * kQueueStride * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(s->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned));     // zero once: every march launch leaves them zero
+    hipError_t e = pool_malloc((void **)&s->d_acc, (size_t)cam->x_pixel_number * cam->y_pixel_number * sizeof(double));
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     {
         int dev = 0, cus = 0;
