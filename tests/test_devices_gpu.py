@@ -76,3 +76,22 @@ def test_staged_sum_when_peer_reads_are_off(photon, oracle, workdir, monkeypatch
     monkeypatch.setenv("PHOTON_PEER_READS", "0")
     got = photon.render(call).astype(np.float64)
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-5
+
+
+def test_eight_shards_repeat_the_same_image(photon, workdir, monkeypatch):
+    """Forty calls of the C3 job as eight shards on one device: every one returns the first call's image.  What this
+    holds: nothing a scene sets up on the NULL stream may still be pending when its march starts on the worker's
+    non-blocking stream.  hipMemset returns when its fill kernel is queued (tools/ubench/null_stream_memset.hip); with the
+    other shards' persistent march waves holding every wave slot that fill waits next to the shard's own march, and a
+    scene's work queues zeroed that way were, in 3 of 60 C4 calls, zeroed after groups had been handed out (hand-off errors;
+    once an image off by 6e-5 with no error).  Counters and queues are now part of the scene's host-to-device copy."""
+    monkeypatch.setenv("PHOTON_INTERP", "cubic")
+    monkeypatch.setenv("PHOTON_DEVICES", "0,0,0,0,0,0,0,0")
+    call = scenes.config("C3", workdir)
+    first = photon.render(call).astype(np.float64)
+    assert first.sum() > 0
+    norm = np.linalg.norm(first)
+    for k in range(40):
+        img = photon.render(call).astype(np.float64)
+        rel = np.linalg.norm(img - first) / norm
+        assert rel <= 1e-7, (k, rel)                          # f64 accumulation: the order of the atomics moves nothing an f32 pixel shows
