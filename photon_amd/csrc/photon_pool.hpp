@@ -22,8 +22,9 @@ hipError_t device_malloc(void **out, size_t bytes);
 
 // Zero `bytes` at `p` on the current device, COMPLETE when the call returns.  hipMemset is not: it queues a fill kernel on
 // the null stream and returns (measured: 9 us, with the fill still 200 ms away behind a full chip), and work launched
-// afterwards on a non-blocking stream is not ordered behind the null stream.  Every zeroing in this library that is not a
-// hipMemsetAsync on the stream of its consumer goes through here (tests/test_sources_lint.py holds the line).
+// afterwards on a non-blocking stream is not ordered behind the null stream (hipMemcpy device-to-device behaves the same;
+// host-to-device and device-to-host copies are complete on return: tools/ubench/null_stream_memset.hip).  Every zeroing in
+// this library that is not a hipMemsetAsync on the stream of its consumer goes through here (tests/test_sources_lint.py holds the line).
 hipError_t device_zero(void *p, size_t bytes);
 
 // a device allocation that is released on every return path

@@ -359,7 +359,7 @@ static int volume_build(const DensitySource &src, int nx, int ny, int nz, const 
     v->grad_max = grad_max;
     if (interpolation == 2) {
         PH_VCHECK(device_malloc((void **)&v->d_coeffs, n * sizeof(f4)));
-        PH_VCHECK(hipMemcpy(v->d_coeffs, v->d_texels, n * sizeof(f4), hipMemcpyDeviceToDevice));
+        PH_VCHECK(hipMemcpyAsync(v->d_coeffs, v->d_texels, n * sizeof(f4), hipMemcpyDeviceToDevice, nullptr));     // null stream, like the prefilter passes behind it
         const size_t sx = 1, sy = (size_t)nx, sz = (size_t)nx * ny;
         auto nblk = [](size_t lines) { return dim3((unsigned)((lines + 255) / 256)); };
         // x lines: (y inner, z outer); y lines: (x inner, z outer); z lines: (x inner, y outer)

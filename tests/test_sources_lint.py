@@ -23,3 +23,16 @@ def test_no_host_side_hipmemset():
             if re.search(r"\bhipMemset(D8|D16|D32|2D|3D)?\s*\(", code):
                 offenders.append(f"{os.path.basename(path)}:{no}: {code.strip()}")
     assert not offenders, "host-asynchronous hipMemset on the null stream:\n" + "\n".join(offenders)
+
+
+def test_no_host_side_device_to_device_hipmemcpy():
+    """The same for hipMemcpy(..., hipMemcpyDeviceToDevice): it returns in 5 us with the copy still queued on the null
+    stream, and a kernel launched afterwards on a non-blocking stream READ THE OLD BYTES in tools/ubench/null_stream_memset.hip.
+    Device-to-device copies are hipMemcpyAsync on a named stream, with the wait (if any) written out."""
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))):
+        text = "".join(code for _, code in code_lines(path))
+        for m in re.finditer(r"\bhipMemcpy\s*\(([^;]*);", text):
+            if "hipMemcpyDeviceToDevice" in m.group(1) or "hipMemcpyDefault" in m.group(1):
+                offenders.append(f"{os.path.basename(path)}: hipMemcpy({' '.join(m.group(1).split())[:100]}")
+    assert not offenders, "host-asynchronous device-to-device hipMemcpy on the null stream:\n" + "\n".join(offenders)

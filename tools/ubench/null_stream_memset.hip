@@ -1,4 +1,4 @@
-// null_stream_memset.hip - is hipMemset (the "synchronous" one, null stream) complete when it returns, and is it ordered
+// null_stream_memset.hip - are hipMemset / hipMemcpy (the "synchronous" ones, null stream) complete when they return, and ordered
 // before a kernel launched afterwards on a NON-BLOCKING stream?  The chip is kept full by a spinning kernel on another
 // non-blocking stream (every wave slot taken), so a fill KERNEL cannot run until that one ends.
 //     hipcc --offload-arch=gfx950 -O2 -o null_stream_memset null_stream_memset.hip && ./null_stream_memset
@@ -23,10 +23,11 @@ int main() {
     hipStream_t a, b;
     CK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
-    unsigned *d = nullptr, *out = nullptr;
-    CK(hipMalloc(&d, 4096)); CK(hipMalloc(&out, 8));
+    unsigned *d = nullptr, *out = nullptr, *dz = nullptr;
+    CK(hipMalloc(&d, 4096)); CK(hipMalloc(&out, 8)); CK(hipMalloc(&dz, 4096));
     std::vector<unsigned> ones(1024, 0xffffffffu), zeros(1024, 0u);
-    for (int form = 0; form < 3; form++) {
+    CK(hipMemcpy(dz, zeros.data(), 4096, hipMemcpyHostToDevice));
+    for (int form = 0; form < 4; form++) {
         CK(hipMemcpy(d, ones.data(), 4096, hipMemcpyHostToDevice));
         CK(hipDeviceSynchronize());
         hipLaunchKernelGGL(spin, dim3(512), dim3(1024), 0, a, 20000000ull);             // 200 ms, 2 x 1024 threads on each of 256 CUs
@@ -35,6 +36,7 @@ int main() {
         if (form == 0) CK(hipMemset(d, 0, 4096));
         if (form == 1) CK(hipMemcpy(d, zeros.data(), 4096, hipMemcpyHostToDevice));
         if (form == 2) { CK(hipMemset(d, 0, 4096)); CK(hipStreamSynchronize(nullptr)); }
+        if (form == 3) CK(hipMemcpy(d, dz, 4096, hipMemcpyDeviceToDevice));
         const double t_call = ms_since(t0);
         hipLaunchKernelGGL(probe, dim3(1), dim3(1), 0, b, d, out);                      // no ordering with the null stream
         CK(hipGetLastError());
@@ -44,7 +46,7 @@ int main() {
         CK(hipMemcpy(h, out, 8, hipMemcpyDeviceToHost));
         CK(hipDeviceSynchronize());
         printf("%-34s returned after %8.3f ms; a kernel on another non-blocking stream then read %08x %08x (probe done at %.3f ms; whole at %.3f ms)\n",
-               form == 0 ? "hipMemset(4 KB)" : form == 1 ? "hipMemcpy(4 KB, host zeros)" : "hipMemset + hipStreamSynchronize(0)", t_call, h[0], h[1], t_probe,
+               form == 0 ? "hipMemset(4 KB)" : form == 1 ? "hipMemcpy(4 KB, host zeros)" : form == 2 ? "hipMemset + hipStreamSynchronize(0)" : "hipMemcpy(4 KB, device to device)", t_call, h[0], h[1], t_probe,
                ms_since(t0));
     }
     return 0;
