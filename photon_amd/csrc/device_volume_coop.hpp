@@ -135,17 +135,17 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
     return acc;
 }
 
-// The coherent tile's 64-tap sum with z-slab 0 served from REGISTERS instead of LDS: `reg` holds, in
-// every 16-lane row of the wave, the 16 texels of slab 0 (lane l: texel l & 15), and its 16 taps are v_fmac_f32_dpp with
-// row_newbcast:k -- every lane multiplies ITS weight with lane k's texel.  16 of the sample's 64 broadcast ds_read_b128
-// disappear; a DPP multiply-add costs more issue time than a plain one (round 2's micro-benchmark: ~1.35x), and the
-// kernel's CYCLES per sample stay what they were -- but the chip, which holds its clock down under this kernel's load,
-// runs the version with fewer LDS reads ~2.7 % faster (same box, round 3: 2130 -> 2188 MHz, 62.4 -> 60.8 ms).
+// The coherent tile's 64-tap sum with z-slabs served from REGISTERS instead of LDS: `reg` (slab 0) and `more` (slabs 1 ..
+// kDppSlabs - 1) hold, in every 16-lane row of the wave, the 16 texels of their slab (lane l: texel l & 15), and a slab's 16
+// taps are v_fmac_f32_dpp with row_newbcast:k -- every lane multiplies ITS weight with lane k's texel.  Sixteen of the
+// sample's 64 broadcast ds_read_b128 disappear per slab; a DPP multiply-add costs more issue time than a plain one (round
+// 2's micro-benchmark: ~1.35x) -- what it buys is power: the chip, which holds its clock down under this kernel's load,
+// runs the version with fewer LDS reads faster (kDppSlabs below).
 // Same taps, same order, same fmaf chain: same bits.
-// ONE asm block: the four reads of slab 1's first row are issued, the 64 register-slab taps run while they are in
+// The FIRST slab's asm block also issues the four reads of the first LDS-fed row: the 64 register taps run while they are in
 // flight, and the block ends on the wait for them (long since landed) -- so the compiler, which does not see LDS
-// traffic inside inline asm, finds nothing outstanding after it.  The DPP operand registers (reg) are not written
-// inside the block; the s_nop covers the EXEC-write / VALU-write -> DPP hazards of whatever precedes it (the compiler's
+// traffic inside inline asm, finds nothing outstanding after it.  The DPP operand registers are not written
+// inside the blocks; the s_nop covers the EXEC-write / VALU-write -> DPP hazards of whatever precedes the first (the compiler's
 // hazard recogniser does not look into inline asm).
 #define PH_DPP_ROW0 \
     "v_mul_f32_dpp %0, %8, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
@@ -224,7 +224,7 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 // five or six waves of the march; the arbiter picks among the ready ones oldest-first, which lets a wave that is in its
 // address arithmetic or its exit tests take issue slots from one that is inside the 64-tap chain -- the chain is what
 // holds the tile's LDS rows and the wave's 80 weight registers live, so the tile turns over later.  Raising the chain
-// above the rest (3 while the DPP block of slab 0 issues, 1 for the LDS-fed slabs 1-3, 1 for the brick chain of the
+// above the rest (3 while the DPP blocks of the register slabs issue, 1 for the LDS-fed slabs, 1 for the brick chain of the
 // lanes outside the tiles) cuts the busy cycles of the headline march by 12 %; the card then runs into its power limit
 // (2.26 -> 2.10 GHz on the boxes measured) and what remains is 57.1 -> 54.1 ms (C3 tricubic), 36.5 -> 35.7 ms (a
 // quarter of C5, brick chain).  The same around the eight-texel trilinear blend LOSES 1 % (16.47 -> 16.62 ms): that
@@ -240,10 +240,34 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #ifndef PHOTON_PRIO_BRICK
 #define PHOTON_PRIO_BRICK 1
 #endif
-__device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const float (&wx)[4], const float (&wy)[4],
+// How many of the cell's four z-slabs are served from registers (1 .. 4; the rest from the tile in LDS).  The DPP form is
+// the dearer instruction to issue, a broadcast ds_read_b128 the dearer one in watts -- and this kernel runs at the board's
+// power limit.  With the chains at a raised wave priority (above), same box, C3 tricubic march | one GPU's eighth | clock:
+//   1 slab 53.88 ms | 6.948 | 2113 MHz     2 slabs 52.53 | 6.818 | 2172     3 slabs 51.84 | 6.838 | 2288     4 slabs 57.47 | 7.579 | 2376
+// (cycles: 1.00, 1.00, 1.04, 1.20).  By rows of four taps on another box -- 8: 51.96, 10: 51.73, 11: 51.60, 12: 51.80, 13: 52.20,
+// 14: 52.89 -- a flat optimum; whole slabs keep the code one loop, and three leave the kernel close to the clock's ceiling,
+// i.e. least exposed to what a particular card's power budget allows (profiles/r05_e_register_slabs.txt).  Round 3 had
+// measured one slab against none without the wave priority: same cycles, +2.7 % clock.
+#ifndef PHOTON_DPP_SLABS
+#define PHOTON_DPP_SLABS 3
+#endif
+constexpr int kDppSlabs = PHOTON_DPP_SLABS;
+static_assert(kDppSlabs >= 1 && kDppSlabs <= 4, "PHOTON_DPP_SLABS");
+#define PH_DPP_OPERANDS(S, T) \
+            : "=&v"(S.x), "=&v"(S.y), "=&v"(S.z), "=&v"(S.w), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) \
+            : "v"(T.x), "v"(T.y), "v"(T.z), "v"(T.w), "v"(wxy[0][0]), "v"(wxy[0][1]), "v"(wxy[0][2]), "v"(wxy[0][3]), \
+              "v"(wxy[1][0]), "v"(wxy[1][1]), "v"(wxy[1][2]), "v"(wxy[1][3]), "v"(wxy[2][0]), "v"(wxy[2][1]), "v"(wxy[2][2]), \
+              "v"(wxy[2][3]), "v"(wxy[3][0]), "v"(wxy[3][1]), "v"(wxy[3][2]), "v"(wxy[3][3]) \
+            : "memory"
+// one z-slab's sixteen taps from the registers `tex` (its texels, one per lane of every 16-lane row) into s
+__device__ __forceinline__ void dpp_slab(f4 &s, const f4 &tex, const float (&wxy)[4][4]) {
+    float d0, d1, d2, d3;                                           // operand slots 4-7: the read-ahead of the first block, unused here
+    asm volatile(PH_DPP_ROWS_TEXT PH_DPP_OPERANDS(s, tex));
+}
+__device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const f4 (&more)[3], const float (&wx)[4], const float (&wy)[4],
                                                 const float (&wz)[4]) {
     typedef float v4f __attribute__((ext_vector_type(4)));
-    constexpr int R = 4;                                            // rows (of four taps) of z-slab 0 served from registers: all of it
+    constexpr int R = 4 * kDppSlabs;                                // rows (of four taps) served from registers
     float wxy[4][4];
 #pragma unroll
     for (int b = 0; b < 4; b++)
@@ -255,6 +279,7 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
 #if PHOTON_PRIO_TAPS_DPP > 0
     __builtin_amdgcn_s_setprio(PHOTON_PRIO_TAPS_DPP);
 #endif
+    if (R < 16)
     asm volatile(
             "ds_read_b128 %4, %28\n\t"
             "ds_read_b128 %5, %28 offset:" PH_DS_OFF1 "\n\t"
@@ -268,12 +293,22 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
               "v"(wxy[1][0]), "v"(wxy[1][1]), "v"(wxy[1][2]), "v"(wxy[1][3]), "v"(wxy[2][0]), "v"(wxy[2][1]), "v"(wxy[2][2]),
               "v"(wxy[2][3]), "v"(wxy[3][0]), "v"(wxy[3][1]), "v"(wxy[3][2]), "v"(wxy[3][3]), "v"(lds)
             : "memory");
+    else {                                                          // every row from registers: nothing to read ahead
+        asm volatile("s_nop 4");
+        dpp_slab(s, reg, wxy);
+        t0 = t1 = t2 = t3 = v4f{0, 0, 0, 0};
+    }
+    f4 acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};                 // slab 0 complete
+#pragma unroll
+    for (int z = 1; z < kDppSlabs; z++) {                           // the next slabs the same way, from their registers
+        dpp_slab(s, more[z - 1], wxy);
+        acc = f4{fmaf(wz[z], s.x, acc.x), fmaf(wz[z], s.y, acc.y), fmaf(wz[z], s.z, acc.z), fmaf(wz[z], s.w, acc.w)};
+        asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
+    }
 #if PHOTON_PRIO_TAPS_DPP != PHOTON_PRIO_TAPS_LDS
     __builtin_amdgcn_s_setprio(PHOTON_PRIO_TAPS_LDS);
 #endif
     f4 t[4] = {f4{t0.x, t0.y, t0.z, t0.w}, f4{t1.x, t1.y, t1.z, t1.w}, f4{t2.x, t2.y, t2.z, t2.w}, f4{t3.x, t3.y, t3.z, t3.w}};
-    f4 acc = f4{0, 0, 0, 0};
-    acc = f4{wz[0] * s.x, wz[0] * s.y, wz[0] * s.z, wz[0] * s.w};                 // slab 0 complete
     float w0 = wxy[0][0];
 #pragma unroll
     for (int r = R; r < 16; r++) {                                  // the rest of the tile from LDS, as in cubic_taps_lds
@@ -314,9 +349,9 @@ __device__ __forceinline__ bool lane_of(unsigned long long mask) { return __buil
 // ti, tj, tk: the tricubic sampler's current CELL (the one the register slab belongs to), the trilinear sampler's column and
 // base layer (tile A; ui, uj, uk: tile B).  ci, cj, k0, coff (tricubic, tiles deeper than one cell): the tile's column (bit patterns), the k of its first
 // cell, and the current cell's texel offset in it.
-struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; int ci, cj, k0, coff; int ui, uj, uk; };      // reg: z-slab 0 of the current cell in registers (per lane)
+struct Parked { int ti, tj, tk; int bi, bj, bk; f4 reg; int ci, cj, k0, coff; int ui, uj, uk; f4 more[3]; };      // reg: z-slab 0 of the current cell in registers (per lane); more: z-slabs 1 .. kDppSlabs - 1 likewise
 __device__ __forceinline__ Parked parked_none() {                // 0x7fffffff: a NaN pattern no floor() of a sampled coordinate has
-    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}, 0x7fffffff, 0x7fffffff, 0, 0, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    return Parked{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, f4{0, 0, 0, 0}, 0x7fffffff, 0x7fffffff, 0, 0, 0x7fffffff, 0x7fffffff, 0x7fffffff, {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}}};
 }
 
 // Block coherence of a wave's sample: the first sampling lane leads; the wave is coherent when every sampling lane
@@ -352,8 +387,8 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         // cone straddles a texel boundary).  The parked tile is 4 x 4 texels wide and TL layers deep: TL - 3 cells of the
         // column the wave travels along (a ray advances a cell per RK4 iteration: the one-cell tile of rounds 1-3 was
         // fetched 0.35 times per sample), lane l <-> texel (l&3, (l>>2)&3, l>>4) of every four layers, clamp-to-edge per
-        // texel.  The chain reads its cell with broadcast reads at the cell's offset in the tile; z-slab 0 of the CURRENT
-        // cell sits in registers (parked.reg) and is re-read from LDS when the wave moves on to the next cell of the
+        // texel.  The chain reads its cell with broadcast reads at the cell's offset in the tile; the first z-slabs of the CURRENT
+        // cell sit in registers (parked.reg, parked.more) and are re-read from LDS when the wave moves on to the next cell of the
         // tile.  The test is against the current cell first (no leader, no readlane); a wave that went to the bricks
         // forgets its cell and skips that test while it stays incoherent.
         constexpr int TL = kCubicTileLayers;
@@ -391,6 +426,8 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
                 }
                 parked.coff = dz * 16;
                 parked.reg = ldtexel(blk + parked.coff + (lane & 15));   // slab 0 of the cell, into every 16-lane row
+#pragma unroll
+                for (int z = 1; z < kDppSlabs; z++) parked.more[z - 1] = ldtexel(blk + parked.coff + 16 * z + (lane & 15));
                 parked.ti = c.i; parked.tj = c.j; parked.tk = c.k;
                 hit = true;
             }
@@ -398,7 +435,7 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
         if (hit) {
             path_stat(0);
             const f4 *cell = blk + parked.coff;
-            const f4 acc = cubic_taps_hybrid(cell, parked.reg, wx, wy, wz);
+            const f4 acc = cubic_taps_hybrid(cell, parked.reg, parked.more, wx, wy, wz);
             __builtin_amdgcn_wave_barrier();
             return acc;
         }

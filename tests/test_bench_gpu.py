@@ -33,7 +33,7 @@ def test_bench_line_contract(photon):
     # the bound is instruction issue, priced with counters measured in THIS run (child rocprofv3 --pmc passes)
     assert r["bound"] == "valu_issue+power" and 0 < r["frac"] <= 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
     v = r["valu_issue"]
-    assert 300 < v["valu_per_wave_sample"] < 600 and 20 < v["lds_per_wave_sample"] < 70 and v["cycles_per_inst"] > 2.0
+    assert 300 < v["valu_per_wave_sample"] < 600 and 10 < v["lds_per_wave_sample"] < 70 and v["cycles_per_inst"] > 2.0
     assert v["frac"] == pytest.approx(r["frac"], rel=2e-3)
     assert 0 < r["frac_vs_nominal_issue"]["frac"] < r["frac"]             # the nominal yardstick (2 cycles at 2.4 GHz) is the stricter one
     assert 0 < r["lds_pipe"]["frac"] <= 1.0
