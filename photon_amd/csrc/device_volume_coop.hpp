@@ -223,19 +223,22 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 // WAVE PRIORITY of the tap chains (s_setprio; 0 = the level every other instruction of the march runs at).  A SIMD holds
 // five or six waves of the march; the arbiter picks among the ready ones oldest-first, which lets a wave that is in its
 // address arithmetic or its exit tests take issue slots from one that is inside the 64-tap chain -- the chain is what
-// holds the tile's LDS rows and the wave's 80 weight registers live, so the tile turns over later.  Raising the chain
-// above the rest (3 while the DPP blocks of the register slabs issue, 1 for the LDS-fed slabs, 1 for the brick chain of the
-// lanes outside the tiles) cuts the busy cycles of the headline march by 12 %; the card then runs into its power limit
-// (2.26 -> 2.10 GHz on the boxes measured) and what remains is 57.1 -> 54.1 ms (C3 tricubic), 36.5 -> 35.7 ms (a
-// quarter of C5, brick chain).  The same around the eight-texel trilinear blend LOSES 1 % (16.47 -> 16.62 ms): that
-// chain is 40 instructions, the arbitration change costs more than it gives, it stays at level 0.  Levels compared on
-// one box (profiles/r05_d_priority.txt): 3/0, 2/0, 1/0 all 54.5; 3/1, 2/1 53.8-54.1; 1/1 55.2; 0/3 (only the LDS-fed
-// part raised) 58.8, worse than none.  Results do not depend on it: priority orders issue, not arithmetic.
+// holds the tile's LDS rows and the wave's weight registers live, so the tile turns over later.  Raising the DPP blocks
+// above the rest cut the busy cycles of the headline march by 12 % when ONE slab came from registers (levels compared on
+// one box then, DPP block / LDS-fed slabs: 3/0, 2/0, 1/0 all 54.5 ms; 3/1, 2/1 53.8-54.1; 1/1 55.2; 0/3 58.8; none 57.1;
+// profiles/r05_d_priority.txt); the card answered with a lower clock (2.26 -> 2.10 GHz: its power limit), which is what
+// moving two more slabs into registers then addressed (kDppSlabs below).  With THREE register slabs the chain is mostly DPP
+// forms and cannot do without: none 67.95 ms, 1/1 57.10, 3/3 55.89, 2/1 53.47, 3/1 53.40, 3/0 53.17 (one GPU's eighth
+// 9.37, 7.49, 7.38, 7.09, 7.06, 7.00; profiles/r05_e_register_slabs.txt) -- the DPP blocks at 3, the LDS-fed slab at
+// the common level.  The brick chain of the lanes outside the tiles at 1: a quarter of C5 36.5 -> 35.7 ms.  The same
+// around the eight-texel trilinear blend LOSES 1 % (16.47 -> 16.62 ms): that chain is 40 instructions, the arbitration
+// change costs more than it gives, it stays at level 0.  Results do not depend on any of it: priority orders issue, not
+// arithmetic.
 #ifndef PHOTON_PRIO_TAPS_DPP
 #define PHOTON_PRIO_TAPS_DPP 3
 #endif
 #ifndef PHOTON_PRIO_TAPS_LDS
-#define PHOTON_PRIO_TAPS_LDS 1
+#define PHOTON_PRIO_TAPS_LDS 0
 #endif
 #ifndef PHOTON_PRIO_BRICK
 #define PHOTON_PRIO_BRICK 1
