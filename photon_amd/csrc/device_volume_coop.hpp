@@ -220,20 +220,29 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #define PH_DS_OFF1 "16"
 #define PH_DS_OFF2 "32"
 #define PH_DS_OFF3 "48"
-// WAVE PRIORITY of the tap chains (s_setprio; 0 = the level every other instruction of the march runs at).  A SIMD holds
-// five or six waves of the march; the arbiter picks among the ready ones oldest-first, which lets a wave that is in its
-// address arithmetic or its exit tests take issue slots from one that is inside the 64-tap chain -- the chain is what
-// holds the tile's LDS rows and the wave's weight registers live, so the tile turns over later.  Raising the DPP blocks
-// above the rest cut the busy cycles of the headline march by 12 % when ONE slab came from registers (levels compared on
-// one box then, DPP block / LDS-fed slabs: 3/0, 2/0, 1/0 all 54.5 ms; 3/1, 2/1 53.8-54.1; 1/1 55.2; 0/3 58.8; none 57.1;
-// profiles/r05_d_priority.txt); the card answered with a lower clock (2.26 -> 2.10 GHz: its power limit), which is what
-// moving two more slabs into registers then addressed (kDppSlabs below).  With THREE register slabs the chain is mostly DPP
-// forms and cannot do without: none 67.95 ms, 1/1 57.10, 3/3 55.89, 2/1 53.47, 3/1 53.40, 3/0 53.17 (one GPU's eighth
-// 9.37, 7.49, 7.38, 7.09, 7.06, 7.00; profiles/r05_e_register_slabs.txt) -- the DPP blocks at 3, the LDS-fed slab at
-// the common level.  The brick chain of the lanes outside the tiles at 1: a quarter of C5 36.5 -> 35.7 ms.  The same
-// around the eight-texel trilinear blend LOSES 1 % (16.47 -> 16.62 ms): that chain is 40 instructions, the arbitration
-// change costs more than it gives, it stays at level 0.  Results do not depend on any of it: priority orders issue, not
-// arithmetic.
+// WAVE PRIORITY inside the march (s_setprio).  A SIMD holds five or six waves of the march; the arbiter picks among the
+// ready ones oldest-first, whatever they are about to do.  Four levels are used:
+//   PHOTON_PRIO_BASE 1   everything not named below (stage algebra, weights, tile tests, exits), set when the march starts;
+//   PHOTON_PRIO_TAPS_DPP 3   the DPP blocks of the tricubic chain's register slabs -- what holds the tile's LDS rows and
+//     the wave's weight registers live; with ONE slab in registers raising them cut the busy cycles of the headline march by
+//     12 % (levels then, DPP block / LDS-fed slabs over a base of 0: 3/0, 2/0, 1/0 all 54.5 ms; 3/1, 2/1 53.8-54.1; 1/1 55.2;
+//     0/3 58.8; none 57.1; profiles/r05_d_priority.txt); the card answered with a lower clock (its power limit), which is
+//     what moving two more slabs into registers then addressed (kDppSlabs below).  With THREE register slabs the chain is
+//     mostly DPP forms and cannot do without: none 67.95 ms, 1/1 57.10, 3/3 55.89, 2/1 53.47, 3/1 53.40, 3/0 53.17;
+//   PHOTON_PRIO_TAPS_LDS 0, PHOTON_PRIO_BLEND 0   the stretches that are FED BY LDS READS and wait on them: the tricubic
+//     chain's last slab and the eight-texel trilinear blend run BELOW the base level -- a wave that is about to wait anyway
+//     yields its issue slots.  RK4 trilinear march 15.47 -> 15.09 ms (its eighth 2.064 -> 2.012), Euler trilinear 5.557 ->
+//     5.32; tricubic 52.71 -> 52.41, its eighth 6.930 -> 6.835 (base 1 against base 0; base 2 the same).  RAISING the
+//     trilinear blend above the rest had lost 1 % (15.47 -> 15.62);
+//   PHOTON_PRIO_BRICK 2   the brick chain of the lanes outside the tiles (per-lane LDS reads, 64 of them): one above the
+//     base -- a quarter of C5 36.5 -> 35.7 ms when it was introduced; at the base level 36.6, below it 37.3.
+// Results do not depend on any of it: priority orders issue, not arithmetic (profiles/r05_e_register_slabs.txt, r05_f_priority_base.txt).
+#ifndef PHOTON_PRIO_BASE
+#define PHOTON_PRIO_BASE 1
+#endif
+#ifndef PHOTON_PRIO_BLEND
+#define PHOTON_PRIO_BLEND 0
+#endif
 #ifndef PHOTON_PRIO_TAPS_DPP
 #define PHOTON_PRIO_TAPS_DPP 3
 #endif
@@ -241,7 +250,7 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 #define PHOTON_PRIO_TAPS_LDS 0
 #endif
 #ifndef PHOTON_PRIO_BRICK
-#define PHOTON_PRIO_BRICK 1
+#define PHOTON_PRIO_BRICK 2
 #endif
 // How many of the cell's four z-slabs are served from registers (1 .. 4; the rest from the tile in LDS).  The DPP form is
 // the dearer instruction to issue, a broadcast ds_read_b128 the dearer one in watts -- and this kernel runs at the board's
@@ -279,7 +288,7 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
     v4f t0, t1, t2, t3;
     f4 s;
     const unsigned lds = (unsigned)(size_t)blk + 64u * R;           // LDS byte address of the first row read from the tile
-#if PHOTON_PRIO_TAPS_DPP > 0
+#if PHOTON_PRIO_TAPS_DPP != PHOTON_PRIO_BASE
     __builtin_amdgcn_s_setprio(PHOTON_PRIO_TAPS_DPP);
 #endif
     if (R < 16)
@@ -332,8 +341,8 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
             asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
         }
     }
-#if PHOTON_PRIO_TAPS_LDS > 0
-    __builtin_amdgcn_s_setprio(0);
+#if PHOTON_PRIO_TAPS_LDS != PHOTON_PRIO_BASE
+    __builtin_amdgcn_s_setprio(PHOTON_PRIO_BASE);
 #endif
     return acc;
 }
@@ -481,12 +490,12 @@ __device__ __forceinline__ f4 tex3d_cubic_coop(const VolumeDev &v, const f4 *__r
             parked.bi = ci; parked.bj = cj; parked.bk = ck;
         }
         if (in_brick) {
-#if PHOTON_PRIO_BRICK > 0
+#if PHOTON_PRIO_BRICK != PHOTON_PRIO_BASE
             __builtin_amdgcn_s_setprio(PHOTON_PRIO_BRICK);
 #endif
             acc = cubic_taps_lds<kBrickPitch, kBrickSlab>(brick + (dj * kBrickPitch + di), wx, wy, wz);
-#if PHOTON_PRIO_BRICK > 0
-            __builtin_amdgcn_s_setprio(0);
+#if PHOTON_PRIO_BRICK != PHOTON_PRIO_BASE
+            __builtin_amdgcn_s_setprio(PHOTON_PRIO_BASE);
 #endif
             done = true;
         }
@@ -674,10 +683,16 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
             path_stat(0);
             // q[tc*4 + tb*2 + {0: texel, 1: x-difference}], q = the lane's cell in its tile; same lerp tree as tex3d_linear
             const f4 *q = blk + ((dzq & (unsigned)(NT * TL - 1)) << 2);         // (the mask: lanes that do not sample stay inside the wave's LDS area)
+#if PHOTON_PRIO_BLEND != PHOTON_PRIO_BASE
+            __builtin_amdgcn_s_setprio(PHOTON_PRIO_BLEND);
+#endif
             const f4 c00 = lerp4d(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4d(ldtexel(q + 2), ldtexel(q + 3), a);
             const f4 c01 = lerp4d(ldtexel(q + 4), ldtexel(q + 5), a), c11 = lerp4d(ldtexel(q + 6), ldtexel(q + 7), a);
             const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
             const f4 acc = lerp4(c0, c1, c);
+#if PHOTON_PRIO_BLEND != PHOTON_PRIO_BASE
+            __builtin_amdgcn_s_setprio(PHOTON_PRIO_BASE);
+#endif
             __builtin_amdgcn_wave_barrier();
             return acc;
         }
@@ -1036,8 +1051,16 @@ __device__ __forceinline__ unsigned long long trace_volume_coop(bool has_ray, f3
         }
         if (active) pos_io = pos;
     }
-    if (ALGO == 1) return euler_coop<INTERP, SAVE, NOISE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump, rs);
-    return rk4_coop<INTERP, SAVE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump, rs);
+#if PHOTON_PRIO_BASE > 0
+    __builtin_amdgcn_s_setprio(PHOTON_PRIO_BASE);               // the march's own level: its LDS-fed stretches run BELOW it (see PHOTON_PRIO_*)
+#endif
+    unsigned long long still;
+    if (ALGO == 1) still = euler_coop<INTERP, SAVE, NOISE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, gn, idump, rs);
+    else still = rk4_coop<INTERP, SAVE, QUANT, CNT>(active, pos_io, dir_io, v, tex, blk, scale, mc, idump, rs);
+#if PHOTON_PRIO_BASE > 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    return still;
 }
 
 }  // namespace photon
