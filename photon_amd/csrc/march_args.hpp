@@ -67,9 +67,10 @@ __device__ __forceinline__ void wave_add(unsigned long long *dst, unsigned long 
                                         // 12.49, one GPU's eighth of C3 2.278 -> 2.270 (round 2, 197 instructions per sample: 26.6 -> 27.7 ms); with the
                                         // lean out-of-line gather (device_volume_coop.hpp) 3 / 26 spilled dwords: 16.29 and 2.21 ms.  Seven waves: 16.75
 #ifndef PHOTON_MARCH_WAVES_EULER_LINEAR
-#define PHOTON_MARCH_WAVES_EULER_LINEAR 6   // Euler trilinear: the whole-march kernel needs 71 VGPRs (seven waves per SIMD as it is); the segmented one 83:
-#endif                                      // capped at 80 it spills 2 dwords and runs a sixth wave -- one GPU's eighth 0.849 -> 0.809 ms, a quarter 1.625 ->
-                                            // 1.531 (before the lean out-of-line gather the cap cost 17 spilled dwords: 0.845 -> 0.855)
+#define PHOTON_MARCH_WAVES_EULER_LINEAR 7   // Euler trilinear: the whole-march kernel needs 70 VGPRs (seven waves per SIMD as it is); the segmented one 83:
+#endif                                      // capped at 72 it spills 17 dwords (48 B of scratch per lane) and, with the blend below the march's base priority
+                                            // (device_volume_coop.hpp), still wins with the seventh wave -- C3 Euler march 5.327 -> 5.147 ms, one GPU's eighth
+                                            // 0.791 -> 0.786 (round 5; six waves before that: 0.849 -> 0.809 over five)
 #ifndef PHOTON_MARCH_WAVES_NOISE
 #define PHOTON_MARCH_WAVES_NOISE 3      // the gradient-noise instantiations (Philox + Box-Muller in f64 inside the loop) need ~130 VGPRs: at five
 #endif                                  // waves per SIMD they spilled 46-70 of them into the loop (176-208 B of scratch per lane); three waves, no spill
@@ -78,7 +79,7 @@ template <int ALGO, int INTERP, bool NOISE> constexpr int march_waves() {
 }
 // resident march waves per SIMD of a launch (the segment planner's chip fill)
 inline unsigned march_waves_of(int algorithm, int interp) {
-    return interp == 1 ? (algorithm == 2 ? PHOTON_MARCH_WAVES_LINEAR : 6 /* whole marches: 71 VGPRs */) : PHOTON_MARCH_WAVES;
+    return interp == 1 ? (algorithm == 2 ? PHOTON_MARCH_WAVES_LINEAR : PHOTON_MARCH_WAVES_EULER_LINEAR) : PHOTON_MARCH_WAVES;
 }
 #ifndef PHOTON_MARCH_SEGMENTS
 #define PHOTON_MARCH_SEGMENTS 32        // most segments a ray's march is cut into in launches of several chip fills (launch_march picks)
