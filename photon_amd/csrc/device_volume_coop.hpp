@@ -231,7 +231,8 @@ __device__ __forceinline__ f4 cubic_taps_lds(const f4 *blk, const float (&wx)[4]
 //     mostly DPP forms and cannot do without: none 67.95 ms, 1/1 57.10, 3/3 55.89, 2/1 53.47, 3/1 53.40, 3/0 53.17;
 //   PHOTON_PRIO_TAPS_LDS 0, PHOTON_PRIO_BLEND 0   the stretches that are FED BY LDS READS and wait on them: the tricubic
 //     chain's last slab and the eight-texel trilinear blend run BELOW the base level -- a wave that is about to wait anyway
-//     yields its issue slots.  RK4 trilinear march 15.47 -> 15.09 ms (its eighth 2.064 -> 2.012), Euler trilinear 5.557 ->
+//     (tile and brick alike: a quarter of C5 through the trilinear sampler 12.95 ms with the brick's blend at the base
+//     level, 12.53 below it, 13.25 above) yields its issue slots.  RK4 trilinear march 15.47 -> 15.09 ms (its eighth 2.064 -> 2.012), Euler trilinear 5.557 ->
 //     5.32; tricubic 52.71 -> 52.41, its eighth 6.930 -> 6.835 (base 1 against base 0; base 2 the same).  RAISING the
 //     trilinear blend above the rest had lost 1 % (15.47 -> 15.62);
 //   PHOTON_PRIO_BRICK 2   the brick chain of the lanes outside the tiles (per-lane LDS reads, 64 of them): one above the
@@ -733,12 +734,18 @@ __device__ __forceinline__ f4 tex3d_linear_coop(const VolumeDev &v, const f4 *__
             parked.bi = ci; parked.bj = cj; parked.bk = ck;
         }
         if (in_brick) {
+#if PHOTON_PRIO_BLEND != PHOTON_PRIO_BASE
+            __builtin_amdgcn_s_setprio(PHOTON_PRIO_BLEND);     // LDS-fed, like the tile's blend: below the march's base level
+#endif
             const f4 *q = brick + (dj * kBrickPitch + di);
             const f4 c00 = lerp4(ldtexel(q), ldtexel(q + 1), a), c10 = lerp4(ldtexel(q + kBrickPitch), ldtexel(q + kBrickPitch + 1), a);
             const f4 c01 = lerp4(ldtexel(q + kBrickSlab), ldtexel(q + kBrickSlab + 1), a),
                      c11 = lerp4(ldtexel(q + kBrickSlab + kBrickPitch), ldtexel(q + kBrickSlab + kBrickPitch + 1), a);
             const f4 c0 = lerp4(c00, c10, b), c1 = lerp4(c01, c11, b);
             acc = lerp4(c0, c1, c);
+#if PHOTON_PRIO_BLEND != PHOTON_PRIO_BASE
+            __builtin_amdgcn_s_setprio(PHOTON_PRIO_BASE);
+#endif
             done = true;
         }
         __builtin_amdgcn_wave_barrier();

@@ -1,6 +1,6 @@
 """C5 (Mie PIV + density volume, 1e6 polydisperse particles x 40 rays = 4e7 rays, 256^3 tricubic RK4) on ONE GPU:
 device-resident trace and the PCIe-inclusive start_ray_tracing call (scene upload, device Morton sort, image in / out).
-    python tools/c5_full.py [scale]"""
+    python tools/c5_full.py [scale [interpolation: 2 = tricubic (default), 1 = trilinear]]"""
 import json
 import os
 import sys
@@ -13,6 +13,7 @@ from photon_amd import scenes  # noqa: E402
 from photon_amd.library import PhotonLibrary  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+interp = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 assert torch.cuda.is_available()
 lib = PhotonLibrary()
 work = os.path.join(tempfile.gettempdir(), "photon_bench")
@@ -21,14 +22,14 @@ t0 = time.perf_counter()
 call = scenes.config("C5", work, scale=scale)
 t1 = time.perf_counter()
 scene = lib.scene_create(call)
-vol = lib.volume_load_nrrd(call.density_grad_filename, 2)
+vol = lib.volume_load_nrrd(call.density_grad_filename, interp)
 H, W = call.image_shape
 img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
 t2 = time.perf_counter()
 st = scene.trace(img.data_ptr(), vol, 2, want_stats=True)       # first trace: includes the device Morton sort of the sources
 t3 = time.perf_counter()
 st = scene.trace(img.data_ptr(), vol, 2, want_stats=True)
-os.environ["PHOTON_INTERP"] = "cubic"
+os.environ["PHOTON_INTERP"] = "cubic" if interp == 2 else "linear"
 lib.render(call)                                                # pays the NRRD parse + volume build
 t4 = time.perf_counter()
 lib.render(call)                                                # what photon sees per frame: scene upload + sort + trace + image out
