@@ -152,7 +152,10 @@ static unsigned plan_segments(unsigned groups, unsigned slots, unsigned depth, i
         // 2.315 / 2.376: a hand-off costs them 4.2 us -- they carry the last sampled value along -- and their launches drain
         // over 0.31 of a last piece, in 0.72 us per unit: the full job runs whole, the eighth in 3 pieces).
         const double units = (double)depth * (algorithm == 2 ? 3.0 : 1.0) * (interp == 2 ? 3.0 : 1.0);
-        const double L = (interp == 2 ? 0.82 : 0.72) * units, c = interp == 2 ? 2.9 : 4.2, drain = interp == 2 ? 0.75 : 0.31;
+        // (Round 5: the tricubic kernels march 10 % faster -- 0.74 us per unit --, a hand-off costs what it did: the whole C3 job
+        // moves from five halving pieces to four -- measured 51.53 against 51.50-51.60 ms, 3.29 instead of 3.95 GB of HBM
+        // traffic per launch; three pieces +0.4 %, two +1.0 %; one GPU's eighth stays at eleven: profiles/r05_h_pieces_traffic.txt.)
+        const double L = (interp == 2 ? 0.74 : 0.72) * units, c = interp == 2 ? 2.9 : 4.2, drain = interp == 2 ? 0.75 : 0.31;
         double best_cost = drain * L;
         S = 1;
         for (unsigned k = 2; k <= cap; k++) {
