@@ -275,7 +275,9 @@ static_assert(kDppSlabs >= 1 && kDppSlabs <= 4, "PHOTON_DPP_SLABS");
 // one z-slab's sixteen taps from the registers `tex` (its texels, one per lane of every 16-lane row) into s
 __device__ __forceinline__ void dpp_slab(f4 &s, const f4 &tex, const float (&wxy)[4][4]) {
     float d0, d1, d2, d3;                                           // operand slots 4-7: the read-ahead of the first block, unused here
-    asm volatile(PH_DPP_ROWS_TEXT PH_DPP_OPERANDS(s, tex));
+    // the s_nop: the compiler's hazard recogniser does not look into inline asm -- should it ever write one of these operands
+    // (or EXEC) in the instruction before, the DPP reads would come too early (2 / 5 wait states); non-VALU slots are free here
+    asm volatile("s_nop 4\n\t" PH_DPP_ROWS_TEXT PH_DPP_OPERANDS(s, tex));
 }
 __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, const f4 (&more)[3], const float (&wx)[4], const float (&wy)[4],
                                                 const float (&wz)[4]) {
@@ -307,7 +309,6 @@ __device__ __forceinline__ f4 cubic_taps_hybrid(const f4 *blk, const f4 &reg, co
               "v"(wxy[2][3]), "v"(wxy[3][0]), "v"(wxy[3][1]), "v"(wxy[3][2]), "v"(wxy[3][3]), "v"(lds)
             : "memory");
     else {                                                          // every row from registers: nothing to read ahead
-        asm volatile("s_nop 4");
         dpp_slab(s, reg, wxy);
         t0 = t1 = t2 = t3 = v4f{0, 0, 0, 0};
     }
