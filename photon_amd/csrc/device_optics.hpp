@@ -41,7 +41,8 @@ struct SceneDev {
     const float *mie_angle;             // [num_angles]
     const float *mie_irr;               // [num_angles][num_diameters]
     int num_angles, num_diameters;
-    const float *r1, *r2;               // lens-sample table, shared by all sources (.cu:2006)
+    const float *lens_x, *lens_y;       // where lens sample k meets the lens: the table every source shares (.cu:2006), its double-precision
+                                        // product (.cu:123-124) evaluated once per scene on the host instead of once per ray (photon_scene.hip)
     int num_elements;
     element_data_t elems[kMaxElements];
     float centers[kMaxElements][3];
@@ -107,12 +108,9 @@ __device__ __forceinline__ Ray generate_ray(const SceneDev &sc, int source, int 
     float x_lens, y_lens;
     if (sc.rays_per_source == 1) {
         x_lens = 0.0f; y_lens = 0.0f;
-    } else {                            // .cu:123-124: the whole product is evaluated in double
-        const float r1 = sc.r1[local_ray], r2 = sc.r2[local_ray];
-        double s, c;
-        photon_det_sincos(2 * M_PI * r2, &s, &c);
-        x_lens = (float)(sc.ratio * 1.0 * sc.lens_pitch * r1 * c);
-        y_lens = (float)(sc.ratio * 1.0 * sc.lens_pitch * r1 * s);
+    } else {                            // .cu:123-124, a function of the lens sample only: tabulated per scene
+        x_lens = sc.lens_x[local_ray];
+        y_lens = sc.lens_y[local_ray];
     }
     const float theta = photon_det_atanf(-(x_lens - x_current) / (sc.image_distance - z_current));
     const float phi = photon_det_atanf(-(y_lens - y_current) / (sc.image_distance - z_current));

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <condition_variable>
 #include <thread>
 
 #include "photon_internal.hpp"
@@ -144,8 +145,8 @@ struct CallArgs {
 // PHOTON_DEVICES (SURVEY 8e inside ONE call, for photon's single Python process).  What is distributed is the reference's
 // chunk loop over light-field sources (parallel_ray_tracing.cu:3505-3558): the sources are cut into contiguous,
 // count-balanced blocks, one per listed device; each device's host thread uploads ONLY its block (plus the replicated
-// tables, optics and volume -- the NRRD is parsed once, SharedDensity) and renders into its scene's private f64
-// accumulator on a stream of its own, while the calling thread uploads the caller's image to the first device (peer access
+// tables, optics and volume -- the NRRD is parsed once, SharedDensity); when every thread has done so (a rendezvous) each
+// renders into its scene's private f64 accumulator on a stream of its own, while the calling thread uploads the caller's image to the first device (peer access
 // from the first device to the others has been settled before: once per pair and process).  When the workers are done ONE kernel on the first device sums the
 // accumulators through their peer-mapped pointers and folds the sum into the image (gather_sum_kernel).  A device the
 // first one cannot map (no xGMI / PCIe peer path) has its accumulator copied into a block of the cache first
@@ -171,12 +172,27 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
     const bool allow_direct = !(pr && strcmp(pr, "0") == 0);
     std::vector<char> direct(K, 1);
     for (size_t k = 1; k < K; k++) direct[k] = devices[k] == devices[0] || (allow_direct && peer_access(devices[0], devices[k])) ? 1 : 0;
+    // Two phases with a rendezvous between them: every worker first builds its scene (uploads) and gets its volume, THEN all
+    // start tracing.  With distinct devices the rendezvous costs the spread of eight equal uploads; with a device listed more
+    // than once (rehearsals, tests: all eight on one) it keeps one shard's uploads -- blit kernels -- from queueing behind
+    // another shard's march, whose persistent waves hold every wave slot of the device until they are done.
+    struct Rendezvous {
+        std::mutex m; std::condition_variable cv; size_t waiting = 0, total;
+        explicit Rendezvous(size_t n) : total(n) {}
+        void arrive_and_wait() {
+            std::unique_lock<std::mutex> g(m);
+            if (++waiting == total) cv.notify_all();
+            else cv.wait(g, [&] { return waiting == total; });
+        }
+    } rendezvous(K);
+    std::vector<photon_volume *> volumes(K, nullptr);
     for (size_t k = 0; k < K; k++) {
         workers.emplace_back([&, k]() {
-            rcs[k] = guarded("start_ray_tracing (device worker)", [&]() -> int {
-                const long long b = n_src * (long long)k / (long long)K, e2 = n_src * (long long)(k + 1) / (long long)K;
+            const long long b = n_src * (long long)k / (long long)K, e2 = n_src * (long long)(k + 1) / (long long)K;
+            hipStream_t stream = nullptr;
+            const int rc_setup = guarded("start_ray_tracing (device worker, setup)", [&]() -> int {
                 if (hipSetDevice(devices[k]) != hipSuccess) return 1;
-                hipStream_t stream = worker_stream(devices[k], slot[k]);
+                stream = worker_stream(devices[k], slot[k]);
                 lightfield_source_t shard = *a.lsp;                     // this device's block of the caller's arrays
                 shard.x += b; shard.y += b; shard.z += b; shard.radiance += b; shard.diameter_index += b;
                 shard.num_particles = (int)(e2 - b);
@@ -190,14 +206,18 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
                 photon_scene_set_element_train(sc, element_train_from_env());
                 photon_scene_set_ray_order(sc, ray_order_from_env());
                 photon_scene_set_skip_doomed(sc, skip_doomed_from_env());
-                photon_volume *v = nullptr;
                 int rc = 0;
-                if (a.density) rc = cached_volume(a.density_path, interpolation_from_env(), &v, &shared);
-                if (!rc && v) photon_volume_set_weight_bits(v, weight_bits_from_env());
+                if (a.density) rc = cached_volume(a.density_path, interpolation_from_env(), &volumes[k], &shared);
+                if (!rc && volumes[k]) photon_volume_set_weight_bits(volumes[k], weight_bits_from_env());
+                return rc;
+            });
+            rendezvous.arrive_and_wait();                               // on every path: a worker that failed still arrives
+            if (rc_setup) { rcs[k] = rc_setup; return; }
+            rcs[k] = guarded("start_ray_tracing (device worker)", [&]() -> int {
                 const auto tw = std::chrono::steady_clock::now();
-                if (!rc) rc = trace_accumulate(sc, v, a.algorithm, 0, e2 - b, stream, 0, nullptr);
+                int rc = trace_accumulate(scenes[k], volumes[k], a.algorithm, 0, e2 - b, stream, 0, nullptr);
                 if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = 4;
-                if (!rc) rc = march_error_check(sc);
+                if (!rc) rc = march_error_check(scenes[k]);
                 if (!rc && verbose())
                     fprintf(stderr, "photon: device %d: sources [%lld, %lld) traced in %.3f ms\n", devices[k], b, e2,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count());

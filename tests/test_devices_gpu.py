@@ -29,7 +29,10 @@ def test_eight_shards_on_one_gpu_cost_and_image(photon, workdir, monkeypatch, in
     """The headline job (C3: 1e7 rays, 256^3) through start_ray_tracing as ONE call and as EIGHT shards side by side
     (PHOTON_DEVICES=0 x 8: eight host threads, eight scenes with shard-only uploads, eight streams, one gather-and-sum):
     same image (f64 accumulation; the shards only change the summation order), and the 8-shard call costs at most 5 %
-    + 0.5 ms more than the single call -- the per-call price of the multi-device path itself."""
+    + 0.5 ms more than the single call -- the per-call price of the multi-device path itself.  With the trilinear sampler the
+    bound is 10 % + 0.5 ms: on ONE GPU the eight shards are eight marches of an eighth each, and an eighth costs more than
+    an eighth of the whole (bench.py, C3_trilinear_eighth share_of_whole 0.92: 8 x 2.04 = 16.3 ms of march against 15.1 for
+    the whole job) -- 7 % that no host path can win back here and that eight GPUs do not pay one after the other."""
     monkeypatch.setenv("PHOTON_INTERP", interp)
     monkeypatch.delenv("PHOTON_DEVICES", raising=False)
     call = scenes.config("C3", workdir)
@@ -39,7 +42,7 @@ def test_eight_shards_on_one_gpu_cost_and_image(photon, workdir, monkeypatch, in
     many_ms, many = _median_ms(photon, call)
     rel = np.linalg.norm(many.astype(np.float64) - one) / np.linalg.norm(one.astype(np.float64))
     assert rel <= 1e-6, rel
-    assert many_ms <= 1.05 * one_ms + 0.5, (one_ms, many_ms)
+    assert many_ms <= (1.05 if interp == "cubic" else 1.10) * one_ms + 0.5, (one_ms, many_ms)
 
 
 def test_seventeen_shards_chain_the_gather(photon, oracle, workdir, monkeypatch):
