@@ -64,6 +64,10 @@ struct SceneDev {
     // point of the lens (every source uses the same lens-sample table, .cu:2006), which is what stays
     // coherent when the cone is as wide as the aperture (PIV through a volume).
     int ray_order;
+    // slots per source of THIS launch and what lens sample each stands for: rays_per_source and the identity (nullptr), or -- the
+    // volume-free path -- only the lens samples that can reach the first element's aperture from any source (photon_scene.hip)
+    int slot_rays;
+    const int *slot_map;
     const int *src_perm;                // spatial order of THIS launch's sources (lens-major only); nullptr = identity
     // index of this scene's source 0 in the caller's source list (PHOTON_DEVICES uploads each device only its
     // shard): keeps the noise generator's per-ray key independent of the sharding
@@ -76,7 +80,7 @@ struct SceneDev {
 // slot of this launch -> source index and lens-sample index; n_src = sources in this launch
 __device__ __forceinline__ void slot_to_ray(const SceneDev &sc, long long src_begin, unsigned n_rays, unsigned r, int &source,
                                             int &local_ray) {
-    const unsigned rps = (unsigned)sc.rays_per_source;
+    const unsigned rps = (unsigned)sc.slot_rays;
     if (sc.ray_order == 0) {
         source = (int)(src_begin + r / rps);
         local_ray = (int)(r % rps);
@@ -86,6 +90,7 @@ __device__ __forceinline__ void slot_to_ray(const SceneDev &sc, long long src_be
         const unsigned k = r % n_src;                                   // src_perm covers exactly this launch's range
         source = sc.src_perm ? sc.src_perm[k] : (int)(src_begin + k);
     }
+    if (sc.slot_map) local_ray = sc.slot_map[local_ray];
 }
 
 struct Ray {                            // light_ray_data_t

@@ -119,6 +119,8 @@ struct photon_scene {
     int ray_order_mode = 2;             // 0 source-major, 1 lens-major, 2 auto (photon_scene_set_ray_order)
     bool skip_doomed = true;            // photon_scene_set_skip_doomed
     float lens_z = 0.f;                 // element 0's centre, for the auto rule
+    const int *d_live = nullptr;        // the lens samples that can reach element 0's aperture from ANY source of this scene, ascending
+    int live_count = 0;                 // (part of the upload block); == rays_per_source when none can be ruled out (or nothing is known)
     PermEntry perms[4];                 // spatial (Morton) orders of the lens-major launch ranges seen last
     unsigned long long perm_clock = 0;
     photon_sort_scratch sort_scratch;   // keys / indices / radix-sort temporaries, grown on demand (photon_sort.hip)

@@ -289,6 +289,56 @@ int photon_sources_download(const photon_sources_t *src, float *x, float *y, flo
     return 0;
 }
 
+// The lens samples that CAN reach the aperture of the first element from some source of this scene.  The reference kills a
+// ray whose hit on that element's front surface (a sphere, 'l', or a plane, 't') lies more than pitch / 2 from the axis
+// (.cu:447, 560-566), and aims ray k of every source at the SAME point P_k = (x_lens, y_lens) of the plane z = image_distance
+// (.cu:123-141: x(z) = x_s + tan(theta) (z_s - z) with tan(theta) = -(x_lens - x_s) / (image_distance - z_s)), with
+// |P_k| up to ratio x pitch: a full-aperture cone loses half its rays there, the same ones for every source.  A ray through P_k
+// that hit the surface at axis distance rho <= pitch / 2 and height z_h would have |P_k| <= rho + |z_h - z_a| slope, its slope
+// at most (|P_k| + R) / D (R: largest axis distance of a source, D: smallest source-plane distance along z) and z_h within dz
+// of the plane (the element's vertex plane +- its sag at pitch / 2).  So sample k is DEAD for every source when
+//     |P_k| (1 - dz / D) - dz R / D > pitch / 2 + slack        (slack: a thousandth of the pitch, for the f32 rounding of the aim)
+// and only the others are launched where nothing else needs the dead rays (launch_chunk: no volume, no dumps, reference element
+// path).  Everything in double, from the caller's arrays; geometries this does not cover (tilted or off-axis element, sources
+// generated on the device, a degenerate sphere) return every sample.
+static std::vector<int> live_lens_samples(const std::vector<float> &lx, const std::vector<float> &ly, const lightfield_source_t *lsp,
+                                          bool generated, size_t n_sources, float image_distance, int num_elements, const element_data_t *edp,
+                                          const double (*center)[3], const double (*plane)[4]) {
+    std::vector<int> all(lx.size());
+    for (size_t k = 0; k < all.size(); k++) all[k] = (int)k;
+    if (generated || n_sources == 0 || num_elements < 1 || lx.size() < 2) return all;
+    const char type = edp[0].element_type;
+    const double pitch = edp[0].element_geometry.pitch;
+    if ((type != 'l' && type != 't') || !(pitch > 0)) return all;
+    if (plane[0][0] != 0.0 || plane[0][1] != 0.0 || plane[0][2] == 0.0 || center[0][0] != 0.0 || center[0][1] != 0.0) return all;
+    const double za = image_distance;
+    double dz;
+    if (type == 't') {
+        dz = fabs(-plane[0][3] / plane[0][2] - za);
+    } else {
+        const double R = fabs((double)edp[0].element_geometry.front_surface_radius), t = fabs(edp[0].element_geometry.vertex_distance);
+        if (!(R > pitch / 2) || !(t == t)) return all;
+        const double sag = R - sqrt(R * R - pitch * pitch / 4);
+        dz = fabs(center[0][2] - za) + t / 2 + sag;
+    }
+    double rmax = 0, dmin = HUGE_VAL;
+    for (size_t i = 0; i < n_sources; i++) {
+        const double x = lsp->x[i], y = lsp->y[i], r = sqrt(x * x + y * y), dd = fabs(za - (double)lsp->z[i]);
+        if (!(r == r) || !(dd == dd)) return all;                      // a NaN source: leave everything to the kernels
+        rmax = std::max(rmax, r);
+        dmin = std::min(dmin, dd);
+    }
+    if (!(dz == dz) || !(dmin > 16 * dz)) return all;
+    std::vector<int> live;
+    for (size_t k = 0; k < lx.size(); k++) {
+        const double r = sqrt((double)lx[k] * lx[k] + (double)ly[k] * ly[k]);
+        const bool dead = r * (1 - dz / dmin) - dz * rmax / dmin > pitch / 2 + 1e-3 * pitch + 1e-4 * r;
+        if (!dead) live.push_back((int)k);
+    }
+    if (live.empty()) live.push_back(0);                                // a launch of zero rays per source is nobody's friend
+    return live;
+}
+
 static int scene_create_impl(float lens_pitch, float image_distance, const scattering_data_t *sdp,
                              const char *scattering_type_str, const lightfield_source_t *lsp,
                              const photon_sources *generated, int lightray_number_per_particle, float beam_wavelength,
@@ -404,6 +454,12 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         }
         if ((rc = upload(s, pack, lx.data(), lx.size(), &d.lens_x))) return bail(rc);
         if ((rc = upload(s, pack, ly.data(), ly.size(), &d.lens_y))) return bail(rc);
+        // Which lens samples can reach the first element's aperture at all (live_lens_samples below): the rest need not be
+        // launched on the volume-free path -- half of a full-aperture cone.
+        std::vector<int> live = live_lens_samples(lx, ly, lsp, generated != nullptr, ns, image_distance, num_elements, edp, element_center,
+                                                  element_plane_parameters);
+        s->live_count = (int)live.size();
+        if (live.size() < lx.size() && (rc = upload(s, pack, live.data(), live.size(), &s->d_live))) return bail(rc);
     }
     d.num_elements = num_elements;
     {
@@ -420,6 +476,8 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         }
         d.train_mode = 0;
         d.ray_order = 0;
+        d.slot_rays = lightray_number_per_particle;
+        d.slot_map = nullptr;
         d.src_perm = nullptr;
         d.source_base = 0;
         d.doom_margin = 0.f;
@@ -485,6 +543,8 @@ int photon_scene_set_ray_order(photon_scene_t *s, int mode) {
     s->ray_order_mode = mode;
     return 0;
 }
+
+int photon_scene_live_rays(const photon_scene_t *s) { return s ? s->live_count : -1; }
 
 int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {
     if (!s) return 1;

@@ -69,12 +69,12 @@ static bool use_lens_major(const photon_scene *s, const photon_volume *vol, cons
 // the distance still to go (plus the walk-off inside the volume).  Returns that bound, times a safety factor
 // that also covers the tricubic sampler's overshoot and the integrator's error, plus a thousandth of the
 // aperture; 0 when the skip does not apply.
-static float doom_margin(const photon_scene *s, const photon_volume *vol, int algorithm, const DumpDev &dump) {
-    if (!s->skip_doomed || !vol || (algorithm != 1 && algorithm != 2) || dump.final_pos || dump.inter_pos) return 0.f;
-    if (s->dev.train_mode != 0 || s->dev.noise.add_ngrad) return 0.f;
+// the reference's element path (optical_system without the working train) applies element 0 once per single-member group of
+// the sequence: is there one, and is element 0 a lens with an aperture test?
+static bool first_aperture_applies(const photon_scene *s) {
+    if (s->dev.train_mode != 0) return false;
     const char type = s->dev.elems[0].element_type;
-    if (type != 'l' && type != 't') return 0.f;
-    // the reference path applies element 0 once per single-member group: there must be one
+    if (type != 'l' && type != 't') return false;
     bool applied = false;
     const int n = std::min(s->dev.num_elements, kMaxElements);
     int seq = 0;
@@ -84,7 +84,12 @@ static float doom_margin(const photon_scene *s, const photon_volume *vol, int al
         for (int k = 0; k < n; k++) count += (seq - s->dev.sys_index[k] == idx);
         applied = count == 1;
     }
-    if (!applied) return 0.f;
+    return applied;
+}
+
+static float doom_margin(const photon_scene *s, const photon_volume *vol, int algorithm, const DumpDev &dump) {
+    if (!s->skip_doomed || !vol || (algorithm != 1 && algorithm != 2) || dump.final_pos || dump.inter_pos) return 0.f;
+    if (s->dev.noise.add_ngrad || !first_aperture_applies(s)) return 0.f;
     const VolumeDev &v = vol->dev;
     const double ex = (double)v.max_bound.x - v.min_bound.x, ey = (double)v.max_bound.y - v.min_bound.y,
                  ez = (double)v.max_bound.z - v.min_bound.z;
@@ -110,7 +115,13 @@ int begin_accumulate(photon_scene *s, hipStream_t stream) {
 
 int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
                         long long src_end, DumpDev dump, hipStream_t stream, hipEvent_t ev_march_begin, hipEvent_t ev_march_end) {
-    const unsigned long long n64 = (unsigned long long)(src_end - src_begin) * (unsigned)s->dev.rays_per_source;
+    // Without a volume only the lens samples that can reach the first aperture are launched (photon_scene.hip, live_lens_samples):
+    // the dead ones would be generated, meet the element's front surface and be dropped -- half of a full-aperture PIV cone.
+    const bool live_only = !vol && s->skip_doomed && s->d_live && s->live_count < s->dev.rays_per_source && !dump.final_pos &&
+                           !dump.inter_pos && first_aperture_applies(s);
+    s->dev.slot_rays = live_only ? s->live_count : s->dev.rays_per_source;
+    s->dev.slot_map = live_only ? s->d_live : nullptr;
+    const unsigned long long n64 = (unsigned long long)(src_end - src_begin) * (unsigned)s->dev.slot_rays;
     if (n64 == 0) return 0;
     if (n64 > kMaxRaysPerLaunch) {
         fprintf(stderr, "photon: a launch of %llu rays (sources [%lld, %lld) x %d) exceeds the %u-ray limit per launch\n", n64,

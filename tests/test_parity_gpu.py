@@ -1293,3 +1293,60 @@ def test_normal_range_division_and_sqrt_are_exact(photon):
     for got, want in ((q, want_q), (r, want_r)):
         assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got[~np.isnan(want)]), bits(want[~np.isnan(want)]))
     assert s[0] == 0.0 and s[1] == 1.0 and np.isnan(s[2]) and np.isinf(s[3])
+
+
+def _render_skip_pair(photon, call, monkeypatch):
+    out = {}
+    for skip in ("0", "1"):
+        monkeypatch.setenv("PHOTON_SKIP_DOOMED", skip)
+        out[skip] = photon.render(call).astype(np.float64)
+    monkeypatch.delenv("PHOTON_SKIP_DOOMED")
+    return out["0"], out["1"]
+
+
+@pytest.mark.parametrize("variant", ["sample", "wide_field", "thin_lens", "ratio_0.7", "deep_sheet", "tilted_lens"])
+def test_dead_lens_samples_are_not_launched_and_nothing_changes(photon, oracle, monkeypatch, variant):
+    """The volume-free path launches only the lens samples that can reach the first element's aperture from SOME source
+    (photon_scene.hip, live_lens_samples: a bound over all sources of the scene; the reference aims ray k of every source at
+    the same point of the lens plane, parallel_ray_tracing.cu:123-141, and kills what meets the front surface beyond pitch / 2,
+    :447, 560-566).  A ray that is not launched adds nothing; so the image with the skip must equal the image without it BIT
+    FOR BIT (the surviving rays' increments are the same f32 numbers, added in f64) -- with sources far off the axis, a sheet
+    as deep as the working distance allows, a thin lens, a cone that only just overfills the aperture -- and must equal the
+    oracle's, which launches everything.  A tilted first element is outside what the bound covers: every sample launched."""
+    kw = dict(n_particles=90, rays_per_source=3000, mie=True, seed=11)
+    if variant == "ratio_0.7":
+        kw["ray_cone_pitch_ratio"] = 0.7
+    if variant == "wide_field":
+        kw["field_half_width"] = 3.0e5                      # sources up to 4.2e5 um off the axis: most miss the sensor, the bound must still hold
+    call = scenes.piv_scene(**kw)
+    if variant == "thin_lens":
+        call.elements[0]["element_type"] = "t"               # its focal length is in the element's properties already
+    if variant == "deep_sheet":
+        rng = np.random.default_rng(5)
+        call.src_z = (call.src_z + rng.uniform(-2.0e5, 2.0e5, call.src_z.size)).astype(call.src_z.dtype)
+    if variant == "tilted_lens":
+        call.element_plane_parameters = np.array([[0.02, 0.0, 1.0, call.element_plane_parameters[0][3]]])
+    scene = photon.scene_create(call)
+    live = scene.live_rays()
+    scene.free()
+    rps = call.lightray_number_per_particle
+    if variant == "tilted_lens":
+        assert live == rps
+    elif variant == "ratio_0.7":
+        assert 0.45 * rps < live < 0.85 * rps, live         # radius uniform in [0, 0.7 pitch]: 5/7 inside pitch / 2, plus the margin
+    else:
+        assert 0.45 * rps < live < 0.62 * rps, live         # radius uniform in [0, pitch]: half inside, plus the margin
+    without, with_skip = _render_skip_pair(photon, call, monkeypatch)
+    assert without.sum() > 0 or variant == "wide_field"
+    assert np.array_equal(with_skip, without), float(np.abs(with_skip - without).max())
+    ref, st = oracle.render(call)
+    if ref.sum() > 0:
+        assert rel_l2(with_skip, ref) <= IMAGE_TOL, rel_l2(with_skip, ref)
+
+
+def test_narrow_cones_keep_every_lens_sample(photon):
+    """BOS (ray_cone_pitch_ratio 1e-4): every lens sample lands well inside the aperture; nothing is ruled out."""
+    call = scenes.bos_scene(n_dots=5, points_per_dot=10, rays_per_source=64)
+    scene = photon.scene_create(call)
+    assert scene.live_rays() == 64
+    scene.free()
