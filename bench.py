@@ -350,6 +350,9 @@ def gpu_other_configs(lib, torch, workdir, with_c4, headline):
             leg["atomics_per_s"] = round(st.sensor_taps / reps / dt, 1)
             leg["atomics_what"] = ("algorithmic: the reference issues one atomicAdd per tap (parallel_ray_tracing.cu:2223-2233); the "
                                    "wave-cooperative splat sums a wave's taps per pixel in f64 first and issues one atomic per pixel and wave")
+            leg["lens_samples_launched"] = {"per_source": scene.live_rays(), "of": int(call.lightray_number_per_particle),
+                                            "what": "rays counts sources x rays per source, as requested; the lens samples that cannot reach the "
+                                                    "first element's aperture from any source are not launched (same image bit for bit)"}
         if whole is not None:
             whole_ms, whole_kernel_ms = whole
             leg["share_of_whole"] = round(whole_ms / 8.0 / (dt * 1e3), 4)
