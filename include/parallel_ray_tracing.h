@@ -331,6 +331,8 @@ int photon_scene_set_ray_order(photon_scene_t *scene, int mode);
  * when none can be ruled out: narrow cones, tilted or off-axis first element, sources generated on the device). */
 int photon_scene_set_skip_doomed(photon_scene_t *scene, int on);
 int photon_scene_live_rays(const photon_scene_t *scene);
+/* the kept lens samples themselves, ascending (out: room for `capacity` >= photon_scene_live_rays entries); returns their number, -1 on a bad argument */
+int photon_scene_live_samples(const photon_scene_t *scene, int *out, int capacity);
 
 /* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.

@@ -121,6 +121,7 @@ struct photon_scene {
     float lens_z = 0.f;                 // element 0's centre, for the auto rule
     const int *d_live = nullptr;        // the lens samples that can reach element 0's aperture from ANY source of this scene, ascending
     int live_count = 0;                 // (part of the upload block); == rays_per_source when none can be ruled out (or nothing is known)
+    std::vector<int> live_host;         // the same list on the host (photon_scene_live_samples: tests hold the bound against exact geometry)
     PermEntry perms[4];                 // spatial (Morton) orders of the lens-major launch ranges seen last
     unsigned long long perm_clock = 0;
     photon_sort_scratch sort_scratch;   // keys / indices / radix-sort temporaries, grown on demand (photon_sort.hip)

@@ -459,6 +459,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         std::vector<int> live = live_lens_samples(lx, ly, lsp, generated != nullptr, ns, image_distance, num_elements, edp, element_center,
                                                   element_plane_parameters);
         s->live_count = (int)live.size();
+        s->live_host = live;
         if (live.size() < lx.size() && (rc = upload(s, pack, live.data(), live.size(), &s->d_live))) return bail(rc);
     }
     d.num_elements = num_elements;
@@ -545,6 +546,11 @@ int photon_scene_set_ray_order(photon_scene_t *s, int mode) {
 }
 
 int photon_scene_live_rays(const photon_scene_t *s) { return s ? s->live_count : -1; }
+int photon_scene_live_samples(const photon_scene_t *s, int *out, int capacity) {
+    if (!s || !out || capacity < s->live_count) return -1;
+    for (int k = 0; k < s->live_count; k++) out[k] = s->live_host[(size_t)k];
+    return s->live_count;
+}
 
 int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {
     if (!s) return 1;

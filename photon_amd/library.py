@@ -20,7 +20,7 @@ from .ray_tracing import (RayTracingCall, bind_start_ray_tracing, camera_design_
 DECLARED_SYMBOLS = (
     "start_ray_tracing", "photon_set_device", "photon_device_pci_bus_id", "photon_rand_table", "photon_volume_load_nrrd",
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
-    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_live_rays", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_chunk", "photon_march_queue_size",
+    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_live_rays", "photon_scene_live_samples", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_chunk", "photon_march_queue_size",
     "photon_scene_set_march_segments", "photon_march_segments_plan", "photon_trim_caches", "photon_trace",
     "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_check", "photon_scene_set_march_profile", "photon_scene_march_profile", "photon_scene_march_profile_raw",
     "photon_trace_volume_rays", "photon_trace_volume_rays_queued", "photon_version",
@@ -484,6 +484,19 @@ class Scene:
         f.argtypes = [ctypes.c_void_p]
         f.restype = ctypes.c_int
         return int(f(self.handle))
+
+    def live_samples(self):
+        """The lens samples a volume-free launch keeps, ascending (photon_scene_live_samples)."""
+        import numpy as np
+        n = self.live_rays()
+        out = np.zeros(max(n, 1), np.int32)
+        f = self._lib.lib.photon_scene_live_samples
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        f.restype = ctypes.c_int
+        got = int(f(self.handle, out.ctypes.data, int(out.size)))
+        if got != n:
+            raise PhotonError(f"photon_scene_live_samples returned {got}, expected {n}")
+        return out[:n]
 
     def set_source_base(self, first_source: int):
         """This scene holds the slice of a job's sources that starts at `first_source` (noise ids stay job-wide)."""

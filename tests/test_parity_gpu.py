@@ -1350,3 +1350,51 @@ def test_narrow_cones_keep_every_lens_sample(photon):
     scene = photon.scene_create(call)
     assert scene.live_rays() == 64
     scene.free()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_dead_lens_samples_against_exact_geometry(photon, seed):
+    """The bound behind the static skip, held against the geometry itself in f64: for randomly placed fields (wide, deep, off
+    centre) EVERY sample the scene rules out, from EVERY source, meets the thick lens's front sphere more than pitch / 2 from
+    the axis (or misses it) -- by more than a micron: the kernels' f32 arithmetic is far inside that.  And the bound is not
+    lazy: of the samples it keeps, those beyond 0.52 pitch are few."""
+    rng = np.random.default_rng(seed)
+    call = scenes.piv_scene(n_particles=400, rays_per_source=4000, mie=False, seed=seed,
+                            field_half_width=float(rng.uniform(5e4, 4e5)))
+    call.src_z = (call.src_z + rng.uniform(-1.5e5, 1.5e5, call.src_z.size)).astype(call.src_z.dtype)
+    call.src_x = (call.src_x + rng.uniform(-1e5, 1e5)).astype(call.src_x.dtype)
+    scene = photon.scene_create(call)
+    live = scene.live_samples()
+    scene.free()
+    rps = call.lightray_number_per_particle
+    dead = np.setdiff1d(np.arange(rps), live)
+    assert 0.3 * rps < dead.size < 0.55 * rps
+    r1, r2 = photon.rand_table(rps)
+    e = call.elements[0]
+    pitch = float(e["element_geometry"]["pitch"])
+    Rf = float(e["element_geometry"]["front_surface_radius"])
+    t = float(e["element_geometry"]["vertex_distance"])
+    zc = float(call.element_center[0][2])
+    ratio = float(call.ray_cone_pitch_ratio)
+    lens_pitch = float(call.lens_pitch)
+    za = float(call.image_distance)
+    px = ratio * lens_pitch * r1.astype(np.float64) * np.cos(2 * np.pi * r2.astype(np.float64))
+    py = ratio * lens_pitch * r1.astype(np.float64) * np.sin(2 * np.pi * r2.astype(np.float64))
+    rad = np.hypot(px, py)
+    assert (rad[live] > 0.52 * pitch).mean() < 0.08                    # nearly everything kept is inside, or just outside, the aperture
+    sx, sy, sz = (np.asarray(a, np.float64)[:, None] for a in (call.src_x, call.src_y, call.src_z))
+    # direction of ray (source, dead sample): through (px, py, za); the front sphere's centre (.cu:507-520)
+    dx, dy, dz = px[dead][None, :] - sx, py[dead][None, :] - sy, za - sz
+    cz = zc + (t / 2.0 - Rf)
+    ox, oy, oz = sx, sy, sz - cz
+    a = dx * dx + dy * dy + dz * dz
+    b = 2 * (dx * ox + dy * oy + dz * oz)
+    c = ox * ox + oy * oy + oz * oz - Rf * Rf
+    disc = b * b - 4 * a * c
+    hit = disc >= 0
+    root = np.sqrt(np.where(hit, disc, 0.0))
+    t1, t2 = (-b + root) / (2 * a), (-b - root) / (2 * a)
+    tt = np.minimum(t1, t2) if Rf > 0 else np.maximum(t1, t2)          # .cu:298-336
+    hx, hy = sx + tt * dx, sy + tt * dy
+    rho = np.hypot(hx, hy)
+    assert (~hit | (rho > pitch / 2.0 + 1.0)).all(), float(rho[hit].min() - pitch / 2.0)
