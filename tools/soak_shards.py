@@ -28,8 +28,8 @@ def main():
     work = os.path.join(tempfile.gettempdir(), "photon_soak")
     os.makedirs(work, exist_ok=True)
     bad = 0
-    for name, n_calls, interps in (("C3", args.calls, ("cubic", "linear")), ("C4", args.c4_calls, ("cubic",))):
-        call = scenes.config(name, work, volume_n=512) if name == "C4" else scenes.config(name, work)
+    for name, n_calls, interps in (("C2", args.calls, ("cubic",)), ("C3", args.calls, ("cubic", "linear")), ("C4", args.c4_calls, ("cubic",))):
+        call = scenes.config(name, work, volume_n=512) if name == "C4" else scenes.config(name, work)      # C2: no volume (one fused kernel)
         for interp in interps:
             os.environ["PHOTON_INTERP"] = interp
             os.environ.pop("PHOTON_DEVICES", None)
