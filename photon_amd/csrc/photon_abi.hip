@@ -181,12 +181,19 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
         explicit Rendezvous(size_t n) : total(n) {}
         void arrive_and_wait() {
             std::unique_lock<std::mutex> g(m);
-            if (++waiting == total) cv.notify_all();
-            else cv.wait(g, [&] { return waiting == total; });
+            if (++waiting >= total) cv.notify_all();
+            else cv.wait(g, [&] { return waiting >= total; });
+        }
+        void expect(size_t n) {                                         // fewer parties after all (a thread could not be started)
+            std::lock_guard<std::mutex> g(m);
+            total = n;
+            if (waiting >= total) cv.notify_all();
         }
     } rendezvous(K);
     std::vector<photon_volume *> volumes(K, nullptr);
-    for (size_t k = 0; k < K; k++) {
+    bool all_started = true;
+    for (size_t k = 0; k < K && all_started; k++) {
+        try {
         workers.emplace_back([&, k]() {
             const long long b = n_src * (long long)k / (long long)K, e2 = n_src * (long long)(k + 1) / (long long)K;
             hipStream_t stream = nullptr;
@@ -224,9 +231,14 @@ int render_on_devices(const std::vector<int> &devices, const CallArgs &a, float 
                 return rc;
             });
         });
+        } catch (const std::exception &ex) {                            // no thread: the ones already running must not wait for it
+            fprintf(stderr, "photon: cannot start the worker thread of device %d (%s); image left untouched\n", devices[k], ex.what());
+            rendezvous.expect(workers.size());
+            all_started = false;
+        }
     }
     // meanwhile, on the calling thread: the caller's image onto the first device
-    int rc = 0;
+    int rc = all_started ? 0 : 1;
     auto check = [&](hipError_t err, int line) {
         if (err != hipSuccess && !rc) {
             fprintf(stderr, "photon: HIP error %d (%s) at %s:%d; image left untouched\n", (int)err, hipGetErrorString(err), __FILE__, line);
