@@ -328,7 +328,8 @@ int photon_scene_set_ray_order(photon_scene_t *scene, int mode);
  * caller's source arrays, with a bound that holds for every source (photon_scene.hip, live_lens_samples); the volume-free
  * PIV frame of the reference's sample data (5e8 rays) 25.6 -> 15.5 ms, the image bit for bit.  rays_launched keeps counting
  * sources x rays_per_source.  photon_scene_live_rays: how many lens samples per source such a launch keeps (rays_per_source
- * when none can be ruled out: narrow cones, tilted or off-axis first element, sources generated on the device). */
+ * when none can be ruled out: narrow cones, tilted or off-axis first element, BOS patterns generated on the device; PIV fields
+ * generated on the device are bounded by the generator's box). */
 int photon_scene_set_skip_doomed(photon_scene_t *scene, int on);
 int photon_scene_live_rays(const photon_scene_t *scene);
 /* the kept lens samples themselves, ascending (out: room for `capacity` >= photon_scene_live_rays entries); returns their number, -1 on a bad argument */

@@ -84,6 +84,10 @@ struct photon_sources {                 // light-field sources generated in HBM 
     float *x = nullptr, *y = nullptr, *z = nullptr;
     double *radiance = nullptr;
     int *diameter_index = nullptr;
+    // where the generator put them, when it can say (the PIV field's box): the largest distance from the z axis and the z range --
+    // what the static skip of dead lens samples needs to know about sources it cannot read (photon_scene.hip, live_lens_samples)
+    bool have_extent = false;
+    double rmax = 0, zmin = 0, zmax = 0;
 };
 
 struct PermEntry { long long begin = -1, end = -1; int *d_perm = nullptr; size_t capacity = 0; unsigned long long stamp = 0; };

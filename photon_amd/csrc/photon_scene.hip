@@ -270,6 +270,14 @@ int photon_sources_piv(uint64_t seed, long long n, const double box_min[3], cons
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(4);
     }
     if (d_cdf) (void)hipFree(d_cdf);
+    {   // the box the particles were drawn from (sources_piv_kernel: X, Y uniform in the box, z = Z + z_object), a rounding to float wider
+        const double ax = std::max(fabs(box_min[0]), fabs(box_max[0])), ay = std::max(fabs(box_min[1]), fabs(box_max[1]));
+        const double z0 = std::min(box_min[2], box_max[2]) + z_object, z1 = std::max(box_min[2], box_max[2]) + z_object;
+        src->rmax = sqrt(ax * ax + ay * ay) * (1 + 1e-6);
+        src->zmin = z0 - 1e-6 * fabs(z0) - 1e-3;
+        src->zmax = z1 + 1e-6 * fabs(z1) + 1e-3;
+        src->have_extent = src->rmax == src->rmax && src->zmin == src->zmin && src->zmax == src->zmax;
+    }
     *out = src;
     return 0;
 }
@@ -299,14 +307,15 @@ int photon_sources_download(const photon_sources_t *src, float *x, float *y, flo
 // of the plane (the element's vertex plane +- its sag at pitch / 2).  So sample k is DEAD for every source when
 //     |P_k| (1 - dz / D) - dz R / D > pitch / 2 + slack        (slack: a thousandth of the pitch, for the f32 rounding of the aim)
 // and only the others are launched where nothing else needs the dead rays (launch_chunk: no volume, no dumps, reference element
-// path).  Everything in double, from the caller's arrays; geometries this does not cover (tilted or off-axis element, sources
-// generated on the device, a degenerate sphere) return every sample.
+// path).  Everything in double, from the caller's arrays -- or, for sources generated on the device, from the box the generator
+// drew them from; geometries this does not cover (tilted or off-axis element, generated BOS patterns, a degenerate sphere)
+// return every sample.
 static std::vector<int> live_lens_samples(const std::vector<float> &lx, const std::vector<float> &ly, const lightfield_source_t *lsp,
-                                          bool generated, size_t n_sources, float image_distance, int num_elements, const element_data_t *edp,
-                                          const double (*center)[3], const double (*plane)[4]) {
+                                          const photon_sources *generated, size_t n_sources, float image_distance, int num_elements,
+                                          const element_data_t *edp, const double (*center)[3], const double (*plane)[4]) {
     std::vector<int> all(lx.size());
     for (size_t k = 0; k < all.size(); k++) all[k] = (int)k;
-    if (generated || n_sources == 0 || num_elements < 1 || lx.size() < 2) return all;
+    if ((generated && !generated->have_extent) || n_sources == 0 || num_elements < 1 || lx.size() < 2) return all;
     const char type = edp[0].element_type;
     const double pitch = edp[0].element_geometry.pitch;
     if ((type != 'l' && type != 't') || !(pitch > 0)) return all;
@@ -322,6 +331,10 @@ static std::vector<int> live_lens_samples(const std::vector<float> &lx, const st
         dz = fabs(center[0][2] - za) + t / 2 + sag;
     }
     double rmax = 0, dmin = HUGE_VAL;
+    if (generated) {                                                    // sources made on the device: the generator's box stands in for them
+        rmax = generated->rmax;
+        dmin = za < generated->zmin ? generated->zmin - za : (za > generated->zmax ? za - generated->zmax : 0.0);
+    } else
     for (size_t i = 0; i < n_sources; i++) {
         const double x = lsp->x[i], y = lsp->y[i], r = sqrt(x * x + y * y), dd = fabs(za - (double)lsp->z[i]);
         if (!(r == r) || !(dd == dd)) return all;                      // a NaN source: leave everything to the kernels
@@ -456,7 +469,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         if ((rc = upload(s, pack, ly.data(), ly.size(), &d.lens_y))) return bail(rc);
         // Which lens samples can reach the first element's aperture at all (live_lens_samples below): the rest need not be
         // launched on the volume-free path -- half of a full-aperture cone.
-        std::vector<int> live = live_lens_samples(lx, ly, lsp, generated != nullptr, ns, image_distance, num_elements, edp, element_center,
+        std::vector<int> live = live_lens_samples(lx, ly, lsp, generated, ns, image_distance, num_elements, edp, element_center,
                                                   element_plane_parameters);
         s->live_count = (int)live.size();
         s->live_host = live;

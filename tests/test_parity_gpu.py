@@ -655,6 +655,7 @@ def test_scene_generation_on_device(photon, oracle, monkeypatch, tmp_path):
     pcall.src_radiance, pcall.src_diameter_index = d["radiance"], d["diameter_index"]
     host_img = photon.render(pcall)
     scene = photon.scene_create_from_sources(pcall, s)
+    assert 80 <= scene.live_rays() <= 125             # of 200 lens samples (about half have r1 <= 0.5): the generator's box stands in for the sources it made
     img = torch.zeros(host_img.size, dtype=torch.float32, device="cuda")
     scene.trace(img.data_ptr())
     assert host_img.any() and np.array_equal(img.cpu().numpy().reshape(host_img.shape), host_img)
