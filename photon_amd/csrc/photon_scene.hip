@@ -456,7 +456,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     // every source (the table is indexed by the ray's number within its source, .cu:2006), so it is evaluated HERE, once per
     // lens sample, with the function the kernels used per ray (photon_det_sincos: the same bits on host and device, which is
     // what the CPU oracle relies on) -- a double-precision sincos and six double multiplies per ray less: ray generation
-    // 0.20 -> 0.13 ms per 1e7 rays, the volume-free PIV path (generation, optics and splat in one kernel) measured in DESIGN 4.2
+    // 0.205 -> 0.184 ms per 1e7 rays (135 -> 121 M VALU instructions per launch), the volume-free PIV frame 25.9 -> 25.5 ms
     {
         std::vector<float> lx(r1.size()), ly(r1.size());
         for (size_t k = 0; k < r1.size(); k++) {
