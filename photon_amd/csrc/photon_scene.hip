@@ -507,7 +507,8 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     // stream (9 us, with the fill itself 200 ms away behind a full chip: tools/ubench/null_stream_memset.hip), and a march
     // launched on a non-blocking stream is not ordered behind the null stream -- with eight shards side by side on one device
     // the fill of one shard's queues waited for wave slots next to that shard's own march and, once in a dozen calls, ran
-    // AFTER the march had started handing out groups (groups marched twice: images off by 6e-5, or doubled).
+    // AFTER the march had started handing out groups (pieces handed out again: 3 of 60 C4 calls refused with hand-off errors, one
+    // image off by 6e-5 with none).
     reserve_zeroed(pack, kCounterBytes / sizeof(unsigned long long), &s->d_counters);
     reserve_zeroed(pack, (size_t)kQueues * kQueueStride, &s->d_queue);
     if ((rc = flush_uploads(s, pack))) return bail(rc);
