@@ -277,6 +277,26 @@ class Oracle:
         self.lib.oracle_single_element(p.shape[0], ctypes.byref(e), _p(c), _p(pl), _p(p), _p(d), float(wavelength), _p(r))
         return p, d, r
 
+    def optical_system(self, elements, centers, planes, sys_index, pos, direction, wavelength, radiance, train_mode=1):
+        """The whole element train on n rays (propagate_rays_through_optical_system, parallel_ray_tracing.cu:1274-1381;
+        train_mode 1 = the working train after perform_ray_tracing_03.py:1419-1485)."""
+        from photon_amd.ray_tracing import element_data_struct
+        n_el = len(elements)
+        arr = (element_data_struct * n_el)()
+        for k, e in enumerate(elements):
+            element_from_dict(e, arr[k])
+        p = np.array(pos, np.float32, order="C")
+        d = np.array(direction, np.float32, order="C")
+        r = np.array(radiance, np.float64, order="C")
+        c = np.ascontiguousarray(centers, np.float32).reshape(n_el, 3)
+        pl = np.ascontiguousarray(planes, np.float32).reshape(n_el, 4)
+        si = np.ascontiguousarray(sys_index, np.int32).reshape(n_el)
+        f = self.lib.oracle_optical_system
+        f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
+        f(p.shape[0], ctypes.addressof(arr), _p(c), _p(pl), _p(si), n_el, int(train_mode), _p(p), _p(d), float(wavelength), _p(r))
+        return p, d, r
+
 
 class OracleVolume:
     def __init__(self, o: Oracle, handle):

@@ -1034,12 +1034,16 @@ Ray single_element(const element_data_t &e, f3 center, const float plane[4], Ray
 // :1331-1333); groups with more than one simultaneous element reach a stub.
 //
 // train_mode 1 is the WORKING train the reference advertises, after the design of
-// its numpy ancestor (perform_ray_tracing_03.py:1254-1485; that code does not run either): groups in
-// decreasing system index; a single-member group goes through ITS element; a group of simultaneous
-// elements (a lenslet array) is split by element plane, the planes are visited in the order the ray
-// meets them, and on each plane the ray goes through the member whose centre is nearest to its
-// intersection point.  No reference output exists for this mode: it is pinned by optics (two thin
-// lenses in contact, tests/) and by GPU-vs-oracle parity only.
+// its numpy ancestor (perform_ray_tracing_03.py:1254-1485): groups in decreasing system index; a
+// single-member group goes through ITS element; a group of simultaneous elements (a lenslet array)
+// is split by element plane, the planes are visited in the order the ray meets them, and on each
+// plane the ray goes through the member whose centre is nearest to its intersection point.
+// Pinning: the numpy ancestor's SEQUENTIAL branch (propogate_rays_through_optical_system, :1419-1485,
+// trains of single-member groups) runs in this image and pins the group order and the per-element
+// chaining (tests/golden/train_f64.npz, made by make_golden.py::train_golden; CPU test
+// test_element_train_vs_reference_numpy, GPU twin in test_parity_gpu.py).  Only its
+// simultaneous-elements branch (:1254-1417, entered through a 1x1 object array at :1436-1446) cannot
+// run, so the lenslet-group walk is pinned by optics (tests/) and GPU-vs-oracle parity only.
 int g_element_train = 0;            // oracle_set_element_train()
 
 Ray optical_system(const element_data_t *elems, const float (*centers)[3], const float (*planes)[4],
@@ -1595,6 +1599,22 @@ void oracle_single_element(int n, const element_data_t *e, const float *center, 
         r.dir = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
         r.wavelength = wavelength; r.radiance = radiance[i];
         r = single_element(*e, mk3(center[0], center[1], center[2]), plane, r);
+        pos[3 * i] = r.pos.x; pos[3 * i + 1] = r.pos.y; pos[3 * i + 2] = r.pos.z;
+        dir[3 * i] = r.dir.x; dir[3 * i + 1] = r.dir.y; dir[3 * i + 2] = r.dir.z;
+        radiance[i] = r.radiance;
+    }
+}
+// whole element train (optical_system above) on n rays; train_mode as oracle_set_element_train
+void oracle_optical_system(int n, const element_data_t *elems, const float *centers, const float *planes,
+                           const int *sys_index, int num_elements, int train_mode, float *pos, float *dir,
+                           float wavelength, double *radiance) {
+    for (int i = 0; i < n; i++) {
+        Ray r;
+        r.pos = mk3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        r.dir = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+        r.wavelength = wavelength; r.radiance = radiance[i];
+        r = optical_system(elems, reinterpret_cast<const float(*)[3]>(centers), reinterpret_cast<const float(*)[4]>(planes),
+                           sys_index, num_elements, r, train_mode);
         pos[3 * i] = r.pos.x; pos[3 * i + 1] = r.pos.y; pos[3 * i + 2] = r.pos.z;
         dir[3 * i] = r.dir.x; dir[3 * i + 1] = r.dir.y; dir[3 * i + 2] = r.dir.z;
         radiance[i] = r.radiance;

@@ -285,9 +285,10 @@ __device__ __forceinline__ float front_axis_distance(const element_data_t &e, f3
     return nanf("");
 }
 
-// The WORKING element train (train_mode 1; the reference advertises it, its device code is a stub and
-// its numpy ancestor perform_ray_tracing_03.py:1254-1485 does not run): groups in decreasing system
-// index; a single-member group goes through ITS element; a group of simultaneous elements (lenslet
+// The WORKING element train (train_mode 1; the reference advertises it, its device code is a stub; the
+// sequential branch of its numpy ancestor, perform_ray_tracing_03.py:1419-1485, runs and pins this one
+// through tests/golden/train_f64.npz, the simultaneous-elements branch :1254-1417 does not): groups in
+// decreasing system index; a single-member group goes through ITS element; a group of simultaneous elements (lenslet
 // array) is split by element plane, planes visited in the order the entering ray meets them, and on
 // each plane the ray goes through the member whose centre is nearest to its intersection point.
 constexpr int kMaxGroupPlanes = 8;

@@ -106,6 +106,59 @@ def parse_dump_pair(folder: str):
     return out
 
 
+# ---- multi-element trains pinned to the reference's own numpy sequencer ------------------------------------------------
+def train_cases():
+    """Trains of single-member groups -- the branch of the reference's numpy sequencer that runs
+    (propogate_rays_through_optical_system, perform_ray_tracing_03.py:1419-1485) -- on a small volume-free PIV scene.
+    Returns {name: RayTracingCall}.  Used by tests/golden/make_golden.py::train_golden (the oracle generates the rays,
+    the REFERENCE propagates them in float64 -> train_f64.npz) and by the CPU / GPU tests.  `a_fwd` and `a_swap` are
+    the same two lenses listed in either array order with the system indices swapped along (the sequencer visits
+    DECREASING system index, :1421-1422, so both are the same physical train); `a_rev` sends the rays through the
+    sensor-side lens first; `d_lens_stop` ends in an aperture (the reference's numpy leaves a ray that passes a stop
+    where it was, the device code moves it to the stop's back plane, .cu:985-1003: same line, so the tests compare
+    lines and sensor hits, not the point along the line)."""
+    import copy
+    import numpy as np
+    from photon_amd import scenes
+    base = scenes.piv_scene(n_particles=24, rays_per_source=96, mie=False, seed=11, field_half_width=2.5e4,
+                            ray_cone_pitch_ratio=0.7)
+    zc = float(base.element_center[0][2])
+    pitch = float(base.elements[0]["element_geometry"]["pitch"])
+
+    def lens(rf, rb, n, t):
+        e = copy.deepcopy(base.elements[0])
+        e["element_type"] = "l"
+        e["element_geometry"].update(front_surface_radius=rf, back_surface_radius=rb, vertex_distance=t, pitch=pitch)
+        e["element_properties"].update(refractive_index=n, transmission_ratio=0.97)
+        return e
+
+    def aperture(p, t):
+        e = copy.deepcopy(base.elements[0])
+        e["element_type"] = "a"
+        e["element_geometry"].update(pitch=p, vertex_distance=t)
+        return e
+
+    A, zA = lens(1.6e5, -2.2e5, 1.52, 400.0), zc + 1500.0
+    B, zB = lens(2.5e5, -1.3e5, 1.476, 450.0), zc - 1500.0
+    trains = {
+        "a_fwd": ([A, B], [zA, zB], [2, 1]),
+        "a_swap": ([B, A], [zB, zA], [1, 2]),
+        "a_rev": ([A, B], [zA, zB], [1, 2]),
+        "b_stop_lens": ([aperture(9000.0, 50.0), copy.deepcopy(base.elements[0])], [zc + 4000.0, zc], [2, 1]),
+        "c_three": ([A, aperture(8000.0, 20.0), B], [zA, zc, zB], [3, 2, 1]),
+        "d_lens_stop": ([copy.deepcopy(base.elements[0]), aperture(7000.0, 30.0)], [zc, zc - 3000.0], [2, 1]),
+    }
+    out = {}
+    for name, (elems, zs, idx) in trains.items():
+        c = copy.deepcopy(base)
+        c.elements = [copy.deepcopy(e) for e in elems]
+        c.element_center = np.array([[0.0, 0.0, z] for z in zs])
+        c.element_plane_parameters = np.array([[0.0, 0.0, 1.0, -z] for z in zs])
+        c.element_system_index = np.array(idx, np.int32)
+        out[name] = c
+    return out
+
+
 # ---- end-to-end BOS displacement: constant density gradient between target and lens ----------------------------------
 def bos_displacement_case(workdir: str, target_px: float = 3.0):
     """A BOS dot pattern rendered without (call 1) and through (call 2) a volume of constant d(rho)/dx sized so that the

@@ -22,6 +22,9 @@ recorder.  What is captured (all DATA, no reference source text):
       (:671)  -> loose (f32-vs-f64) pin of oracle rows a15/a16/a17.
   mie_table.npz
       Mie table + angles from create_mie_scattering_data (run_simulation_02.py:699).
+  train_f64.npz
+      multi-element trains (tests/conftest.py::train_cases) through the reference's numpy sequencer
+      propogate_rays_through_optical_system (:1419-1485, sequential branch)  -> pins oracle row f3.
 
 /root/reference is never read at test time; only these files travel.
 Usage:  python tests/golden/make_golden.py            (needs /root/reference)
@@ -411,10 +414,70 @@ def dumps_golden():
     print("dumps_reference_reader.npz:", {k: v.shape for k, v in out.items() if k.endswith("_x")})
 
 
+def train_golden():
+    """Multi-element trains through the reference's own numpy sequencer, propogate_rays_through_optical_system
+    (perform_ray_tracing_03.py:1419-1485).  Its sequential branch (single-member groups, :1438-1451 ->
+    propogate_rays_through_single_element) runs in this image; the simultaneous-elements branch (:1453-1472) does not.
+    Scenes: tests/conftest.py::train_cases.  The oracle generates each scene's rays in f32 exactly as a render would
+    (source-major, lens sample k uses the srand(10) table entry k); the reference propagates them in float64; stored per
+    case: the rays in, the reference's rays out (NaN = destroyed), radiance out, and where the straight line of each
+    surviving ray meets the sensor plane z = z_sensor (plain geometry on the reference's output, so that the GPU's
+    sensor-position dump can be compared through the C-ABI)."""
+    import run_simulation_02  # noqa: F401  (resolves the circular import)
+    import perform_ray_tracing_03 as prt
+    prt.long = int
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), "..", "oracle"))
+    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from conftest import train_cases
+    from oracle_lib import Oracle
+    o = Oracle()
+    names = {"l": "lens", "a": "aperture"}
+    out = {}
+    for case, call in train_cases().items():
+        L = int(call.lightray_number_per_particle)
+        r1, r2 = o.rand_table(L)
+        pos, direction, rad = [], [], []
+        for s in range(call.num_sources):
+            p, d, r = o.generate_rays(call, s, r1, r2)
+            pos.append(p); direction.append(d); rad.append(r)
+        pos, direction, rad = np.concatenate(pos), np.concatenate(direction), np.concatenate(rad)
+        elements = []
+        for e in call.elements:
+            g, pr = e["element_geometry"], e["element_properties"]
+            elements.append(dict(element_type=names[e["element_type"]],
+                                 element_geometry=dict(pitch=g["pitch"], vertex_distance=g["vertex_distance"],
+                                                       front_surface_radius=g["front_surface_radius"],
+                                                       back_surface_radius=g["back_surface_radius"]),
+                                 element_properties=dict(refractive_index=pr["refractive_index"], abbe_number=np.nan,
+                                                         transmission_ratio=pr.get("transmission_ratio", 1.0),
+                                                         absorbance_rate=pr.get("absorbance_rate", 0.0))))
+        lrd = dict(ray_source_coordinates=pos.astype(np.float64), ray_propogation_direction=direction.astype(np.float64),
+                   ray_wavelength=np.full(len(pos), float(call.beam_wavelength)), ray_radiance=rad.copy())
+        res = prt.propogate_rays_through_optical_system(elements, np.array(call.element_center, np.float64),
+                                                        np.array(call.element_plane_parameters, np.float64),
+                                                        np.array(call.element_system_index), lrd)
+        po = np.asarray(res["ray_source_coordinates"], np.float64)
+        do = np.asarray(res["ray_propogation_direction"], np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            t = (float(call.camera["z_sensor"]) - po[:, 2]) / do[:, 2]
+            hit = po[:, :2] + do[:, :2] * t[:, None]
+        out[f"{case}_in"] = np.concatenate([pos, direction], 1)                     # f32: the oracle's generated rays
+        out[f"{case}_in_radiance"] = rad
+        out[f"{case}_out"] = np.concatenate([po, do], 1)
+        out[f"{case}_out_radiance"] = np.asarray(res["ray_radiance"], np.float64)
+        out[f"{case}_sensor_xy"] = hit
+        print(f"train {case}: {len(pos)} rays, {np.isnan(po[:, 0]).mean():.3f} destroyed")
+    np.savez_compressed(os.path.join(OUT, "train_f64.npz"), **out)
+
+
 def main():
     sys.path.insert(0, os.path.join(REF, "python_codes"))
     if "--dumps-only" in sys.argv:
         dumps_golden()
+        return
+    if "--train-only" in sys.argv:
+        train_golden()
         return
 
     def shrink_piv(p):
@@ -434,6 +497,7 @@ def main():
     lens_golden()
     pins_golden()
     dumps_golden()
+    train_golden()
     # the sample cases at their REAL size (50 000 particles x 10 000 rays; the full dot grid x 500 rays): source arrays
     # + scalars only
     calls, post, params = run_case("piv", lambda p: p["particle_field"].__setitem__("frame_vector", np.array([1])))

@@ -67,6 +67,58 @@ def test_thick_lens_element_vs_reference_numpy(oracle, lens):
     assert np.allclose(rad[ok], lens["lens_out_radiance"][ok])
 
 
+@pytest.mark.parametrize("case", ["a_fwd", "a_swap", "a_rev", "b_stop_lens", "c_three", "d_lens_stop"])
+def test_element_train_vs_reference_numpy(oracle, case):
+    """Row f3: the oracle's working element train (element_train=1) against the reference's OWN numpy sequencer,
+    propogate_rays_through_optical_system (perform_ray_tracing_03.py:1419-1485), on trains of single-member groups --
+    the branch of it that runs (tests/golden/make_golden.py::train_golden).  Pins the group order (decreasing system
+    index, :1421-1422: `a_rev` lands 3 mm from `a_fwd`), that each group goes through ITS element, and the chaining.
+    Same loose f32-vs-f64 bars as the single-element pin above; destroyed-ray masks must be equal."""
+    from conftest import train_cases
+    call = train_cases()[case]
+    g = np.load(os.path.join(GOLDEN, "train_f64.npz"))
+    rays = g[f"{case}_in"]
+    # the stored rays ARE what a render of this scene generates (source-major, lens sample k = table entry k)
+    L = int(call.lightray_number_per_particle)
+    r1, r2 = oracle.rand_table(L)
+    for s in (0, call.num_sources - 1):
+        p0, d0, rad0 = oracle.generate_rays(call, s, r1, r2)
+        assert np.array_equal(p0, rays[s * L:(s + 1) * L, 0:3]) and np.array_equal(d0, rays[s * L:(s + 1) * L, 3:6])
+        assert np.array_equal(rad0, g[f"{case}_in_radiance"][s * L:(s + 1) * L])
+    p, d, rad = oracle.optical_system(call.elements, call.element_center, call.element_plane_parameters,
+                                      call.element_system_index, rays[:, 0:3], rays[:, 3:6], call.beam_wavelength,
+                                      g[f"{case}_in_radiance"], train_mode=1)
+    ref = g[f"{case}_out"]
+    dead_ref, dead = np.isnan(ref[:, 0]), np.isnan(p[:, 0])
+    assert 0.2 < dead_ref.mean() < 0.7
+    assert np.array_equal(dead_ref, dead)
+    ok = ~dead_ref
+    dp = p[ok].astype(np.float64) - ref[ok, 0:3]
+    lateral = dp - (dp * ref[ok, 3:6]).sum(1)[:, None] * ref[ok, 3:6]
+    assert np.linalg.norm(lateral, axis=1).max() < 0.1                    # microns off the reference's line
+    if case != "d_lens_stop":                                             # (a stop moves the point along the line)
+        assert np.abs(dp).max() < 0.5
+    assert np.abs(d[ok].astype(np.float64) - ref[ok, 3:6]).max() < 1e-6   # direction cosines
+    assert np.allclose(rad[ok], g[f"{case}_out_radiance"][ok], rtol=1e-6)
+    t = (float(call.camera["z_sensor"]) - p[ok, 2].astype(np.float64)) / d[ok, 2]
+    hit = p[ok, 0:2] + d[ok, 0:2] * t[:, None]
+    assert np.abs(hit - g[f"{case}_sensor_xy"][ok]).max() < 0.1           # microns on the sensor (pixel = 17)
+    # the reference-as-it-runs mode (element 0 for every group, .cu:1331-1333) is a different function of the input
+    p0, _, _ = oracle.optical_system(call.elements, call.element_center, call.element_plane_parameters,
+                                     call.element_system_index, rays[:, 0:3], rays[:, 3:6], call.beam_wavelength,
+                                     g[f"{case}_in_radiance"], train_mode=0)
+    both = ok & ~np.isnan(p0[:, 0])
+    assert not both.any() or np.abs(p0[both] - p[both]).max() > 10.0
+
+
+def test_element_train_order_is_pinned():
+    """The fixture itself: listing the two lenses in either array order with the indices swapped along is the same
+    train; swapping only the indices is not."""
+    g = np.load(os.path.join(GOLDEN, "train_f64.npz"))
+    assert np.array_equal(g["a_fwd_out"], g["a_swap_out"], equal_nan=True)
+    assert np.nanmax(np.abs(g["a_fwd_sensor_xy"] - g["a_rev_sensor_xy"])) > 100.0
+
+
 def test_sample_bos_volume_is_missed_by_every_ray(oracle):
     """with the shipped sample geometry the slab test fails for every ray, so
     the 'distorted' image only differs from the reference image by the f32 world-transform round

@@ -861,6 +861,46 @@ def test_element_train(photon, oracle, monkeypatch):
     assert rel_l2(g4, o4) <= IMAGE_TOL if o4.any() else not g4.any()
 
 
+@pytest.mark.parametrize("case", ["a_fwd", "a_swap", "a_rev", "b_stop_lens", "c_three", "d_lens_stop"])
+def test_element_train_vs_reference_numpy(photon, oracle, monkeypatch, tmp_path, case):
+    """GPU twin of tests/test_oracle_golden.py::test_element_train_vs_reference_numpy: the scene goes through
+    start_ray_tracing with PHOTON_ELEMENT_TRAIN=sequential and dumps where each ray meets the sensor (pos_0000.bin,
+    .cu:2183-2240); the reference's own numpy sequencer (perform_ray_tracing_03.py:1419-1485) propagated the very same
+    rays in float64 (tests/golden/train_f64.npz).  Bars: destroyed-ray masks equal, sensor hits within 0.1 micron (f32
+    against f64 over ~1e5 micron of travel; a pixel is 17), and bit-exact against the oracle's dump."""
+    from conftest import train_cases
+    call = train_cases()[case]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_f64.npz"))
+    call.save_lightrays, call.num_lightrays_save = True, call.num_rays
+    monkeypatch.setenv("PHOTON_ELEMENT_TRAIN", "sequential")
+    oracle.set_element_train(1)
+    dumps = {}
+    try:
+        for tag, run in (("gpu", lambda c: photon.render(c)), ("cpu", lambda c: oracle.render(c)[0])):
+            pdir, ddir = tmp_path / f"{tag}_pos", tmp_path / f"{tag}_dir"
+            pdir.mkdir()
+            ddir.mkdir()
+            call.lightray_position_save_path, call.lightray_direction_save_path = str(pdir), str(ddir)
+            img = run(call)
+            dumps[tag] = (np.fromfile(pdir / "pos_0000.bin", np.float32).reshape(-1, 3),
+                          np.fromfile(ddir / "dir_0000.bin", np.float32).reshape(-1, 3), img)
+    finally:
+        oracle.set_element_train(0)
+    pos, dirs, img = dumps["gpu"]
+    assert pos.shape[0] == call.num_rays
+    # the dumped direction is the generated one (.cu:2136-2141): the fixture's rays are the rays this render made
+    assert_bit_equal(dirs, g[f"{case}_in"][:, 3:6], "generated directions")
+    ref_xy = g[f"{case}_sensor_xy"]
+    dead_ref = np.isnan(ref_xy[:, 0])
+    half = call.camera["pixel_pitch"] * (call.camera["x_pixel_number"] - 1) / 2.0
+    assert (np.abs(ref_xy[~dead_ref]) < half - 20.0).all()               # every surviving ray lands well inside the sensor
+    assert np.array_equal(np.isnan(pos[:, 0]), dead_ref)
+    assert 0.2 < dead_ref.mean() < 0.7
+    assert np.abs(pos[~dead_ref, 0:2].astype(np.float64) - ref_xy[~dead_ref]).max() < 0.1
+    assert_bit_equal(pos, dumps["cpu"][0], "sensor positions, GPU vs oracle")
+    assert img.any() and rel_l2(img, dumps["cpu"][2]) <= IMAGE_TOL
+
+
 def test_in_library_device_sharding(photon, oracle, small_volume_file, monkeypatch):
     """PHOTON_DEVICES: start_ray_tracing shards the sources over the listed devices (one host thread each,
     private images, one sum at the end -- SURVEY 8e).  One GPU here, so the list repeats device 0: three
