@@ -4,7 +4,6 @@ render_on_devices) -- what is distributed is the reference's chunk loop over lig
 reading the others through their peer-mapped pointers.  On this box every listed device is GPU 0 (same-device pointers
 through the same kernel): the code path of an 8-GPU node, its image, and what the sharding costs over a single call."""
 import os
-import time
 
 import numpy as np
 import pytest
@@ -14,36 +13,21 @@ from photon_amd import scenes
 pytestmark = pytest.mark.gpu
 
 
-def _median_ms(photon, call, reps=3):
-    photon.render(call)                                      # warm-up: volume cached, blocks in the cache
-    times = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        img = photon.render(call)
-        times.append((time.perf_counter() - t0) * 1e3)
-    return sorted(times)[len(times) // 2], img
-
-
 @pytest.mark.parametrize("interp", ["cubic", "linear"])
-def test_eight_shards_on_one_gpu_cost_and_image(photon, workdir, monkeypatch, interp):
+def test_eight_shards_on_one_gpu_image(photon, workdir, monkeypatch, interp):
     """The headline job (C3: 1e7 rays, 256^3) through start_ray_tracing as ONE call and as EIGHT shards side by side
     (PHOTON_DEVICES=0 x 8: eight host threads, eight scenes with shard-only uploads, eight streams, one gather-and-sum):
-    same image (f64 accumulation; the shards only change the summation order), and the price of the multi-device path itself
-    stays small.  What the comparison can hold on ONE GPU: the eight shards are eight marches of an eighth each, and an
-    eighth costs more than an eighth of the whole (bench.py: share_of_whole 0.95 tricubic, 0.92 trilinear -- 8 x 6.8 = 54.4
-    ms of march against 51.9, 8 x 2.04 = 16.3 against 15.1) -- 5 % and 8 % that no host path can win back here and that eight
-    GPUs do not pay one after the other.  Measured 1.02-1.05 (tricubic) and 1.08-1.10 (trilinear) of the single call; the
-    bounds are those shares plus 3 % and 0.5 ms for the path: 1.08 and 1.12."""
+    same image (f64 accumulation; the shards only change the summation order).  What the sharding costs is bounded in
+    tests/test_zz_perf_bounds_gpu.py, after every parity file."""
     monkeypatch.setenv("PHOTON_INTERP", interp)
     monkeypatch.delenv("PHOTON_DEVICES", raising=False)
     call = scenes.config("C3", workdir)
     assert call.num_rays == 10_000_000
-    one_ms, one = _median_ms(photon, call)
+    one = photon.render(call)
     monkeypatch.setenv("PHOTON_DEVICES", "0,0,0,0,0,0,0,0")
-    many_ms, many = _median_ms(photon, call)
+    many = photon.render(call)
     rel = np.linalg.norm(many.astype(np.float64) - one) / np.linalg.norm(one.astype(np.float64))
-    assert rel <= 1e-6, rel
-    assert many_ms <= (1.08 if interp == "cubic" else 1.12) * one_ms + 0.5, (one_ms, many_ms)
+    assert one.any() and rel <= 1e-6, rel
 
 
 def test_seventeen_shards_chain_the_gather(photon, oracle, workdir, monkeypatch):

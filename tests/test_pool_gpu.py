@@ -12,13 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_block_cache_recycles_and_trims(photon, workdir):
-    import torch
-
-    def used_mib():
-        torch.cuda.synchronize()
-        free, total = torch.cuda.mem_get_info()
-        return (total - free) / 2 ** 20
-
+    """Images only: recycled (unzeroed) blocks and an emptied cache change nothing.  The memory figures (nothing new per
+    call, the trim gives the workspace back) are resource bounds: tests/test_zz_perf_bounds_gpu.py."""
     def same(x, y):                                              # up to the order of the f64 atomic adds
         x, y = x.astype(np.float64), y.astype(np.float64)
         return np.linalg.norm(x - y) <= 1e-12 * np.linalg.norm(y)
@@ -28,17 +23,11 @@ def test_block_cache_recycles_and_trims(photon, workdir):
     call = scenes.bos_scene(n_dots=20, points_per_dot=100, rays_per_source=500, density_grad_filename=path)      # 1e6 rays: 32 MB of ray state
     os.environ["PHOTON_INTERP"] = "cubic"
     first = photon.render(call)
-    photon.render(call)
-    a = used_mib()
-    for _ in range(10):
+    for _ in range(5):
         img = photon.render(call)
-    b = used_mib()
-    assert abs(b - a) < 1.0                                      # calls of one shape allocate nothing new
-    assert same(img, first)                                      # recycled (unzeroed) blocks change nothing
+    assert first.any() and same(img, first)                      # recycled (unzeroed) blocks change nothing
     photon.lib.photon_trim_caches.restype = None
     photon.lib.photon_trim_caches()
-    c = used_mib()
-    assert c < b - 30.0                                          # the cached workspace went back to the runtime
     assert same(photon.render(call), first)                      # and the next call simply allocates again
 
 

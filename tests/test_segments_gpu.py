@@ -92,8 +92,8 @@ def test_segment_counters_and_uneven_load(photon, volume_file, interp):
 
 def test_large_launch_is_segmented_by_default(photon, workdir):
     """2e6 rays = 31250 groups, six chip fills, through 128^3 (tricubic RK4: ~1 ms per group): the library segments on its
-    own (its cost model picks 6 pieces here); same counters, same image as whole marches, and the launch's drain -- the
-    average time a wave slot stands empty at its end -- shrinks."""
+    own (its cost model picks 6 pieces here); same counters, same image as whole marches.  (That the launch's drain shrinks is a
+    timing statement: tests/test_zz_perf_bounds_gpu.py.)"""
     import torch
     rho, sp, org = scenes.bos_volume(128)
     volume_file = scenes.write_nrrd(os.path.join(workdir, "seg128.nrrd"), rho, sp, org)
@@ -115,7 +115,6 @@ def test_large_launch_is_segmented_by_default(photon, workdir):
     assert rel_l2(res[-1][0], res[1][0]) <= 1e-12
     whole, seg = res[1][2], res[-1][2]
     print("march profile, whole marches:", whole, "\nmarch profile, segments:", seg, "\nmarch ms:", res[1][1].march_ms, res[-1][1].march_ms)
-    assert whole["launches"] == 1 and seg["launches"] == 1 and seg["waves"] > 1000
-    assert seg["drain_ms"] < whole["drain_ms"]
+    assert whole["launches"] == 1 and seg["launches"] == 1 and seg["waves"] > 1000      # (the drain itself: test_zz_perf_bounds_gpu.py)
     scene.free()
     vol.free()
