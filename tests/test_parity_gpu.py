@@ -1061,7 +1061,7 @@ def test_full_size_c3_properties(photon, oracle, workdir, monkeypatch):
     """1e7 rays through the 256^3 volume (tricubic RK4): (1) sharding the sources in two and
     summing reproduces the single-pass image (what the multi-GPU path relies on); (2) a uniform
     volume deflects nothing: the image equals the no-volume image; (3) counters add up; (4) a 40-source slice of the
-    job equals the oracle's render of those sources through the same 256^3 volume."""
+    job equals the oracle's render of those sources through the same 256^3 volume, for both samplers."""
     import torch
     monkeypatch.setenv("PHOTON_INTERP", "cubic")
     call = scenes.config("C3", workdir)
@@ -1074,16 +1074,22 @@ def test_full_size_c3_properties(photon, oracle, workdir, monkeypatch):
     assert st.rays_launched == call.num_rays
     assert st.rk_iterations >= 250 * call.num_rays and st.volume_samples >= 3 * st.rk_iterations
     assert st.rays_on_sensor == call.num_rays and st.sensor_taps > 10 * call.num_rays
-    # a 40-source slice of the same 256^3 tricubic job against the oracle (the oracle needs ~1 s for it)
-    sl = torch.zeros(H * W, dtype=torch.float32, device="cuda")
-    scene.trace(sl.data_ptr(), vol, 2, 0, 40)
-    torch.cuda.synchronize()
+    # a 40-source slice of the same 256^3 job against the oracle (~1 s of oracle each): tricubic, and trilinear with the
+    # 8-bit weights -- the sampler the reference executes (interpolation_scheme hard-coded 1, parallel_ray_tracing.cu:3330;
+    # trace_rays_through_density_gradients.h:992-1181)
     head = scenes.config("C3", workdir)
     for f in ("src_x", "src_y", "src_z", "src_radiance", "src_diameter_index"):
         setattr(head, f, getattr(head, f)[:40])
-    ref, ost = oracle.render(head, interpolation=2)
-    assert ost.rk_iterations >= 250 * head.num_rays
-    assert rel_l2(sl.cpu().numpy().reshape(H, W), ref) <= IMAGE_TOL
+    for interp in (2, 1):
+        v = vol if interp == 2 else photon.volume_load_nrrd(call.density_grad_filename, 1)
+        sl = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+        sst = scene.trace(sl.data_ptr(), v, 2, 0, 40, want_stats=True)
+        torch.cuda.synchronize()
+        ref, ost = oracle.render(head, interpolation=interp)
+        assert ost.rk_iterations >= 250 * head.num_rays and sst.rk_iterations == ost.rk_iterations
+        assert ref.any() and rel_l2(sl.cpu().numpy().reshape(H, W), ref) <= IMAGE_TOL, interp
+        if interp == 1:
+            v.free()
     halves = torch.zeros(H * W, dtype=torch.float32, device="cuda")
     mid = call.num_sources // 2 + 7
     scene.trace(halves.data_ptr(), vol, 2, 0, mid)
@@ -1143,7 +1149,8 @@ def test_c4_whole_job_on_one_gpu(photon, oracle, workdir, monkeypatch):
     parallel_ray_tracing.cu:3366-3372, 3515-3558): (1) device-resident photon_trace: every ray crosses the grid (>= 509
     iterations) and lands; (2) the same job through start_ray_tracing (host arrays in, host image out) gives the same
     image; (3) so do eight shards side by side (PHOTON_DEVICES=0 x 8: the per-device upload / accumulate / sum path);
-    (4) a 20-source slice equals the oracle's render through the same 512^3 volume."""
+    (4) a 20-source slice equals the oracle's render through the same 512^3 volume -- tricubic, and trilinear with 8-bit
+    weights (what the reference executes)."""
     import torch
     monkeypatch.setenv("PHOTON_INTERP", "cubic")
     call = scenes.config("C4", workdir, volume_n=512)
@@ -1160,8 +1167,14 @@ def test_c4_whole_job_on_one_gpu(photon, oracle, workdir, monkeypatch):
     scene.trace(sl.data_ptr(), vol, 2, 0, 20)
     torch.cuda.synchronize()
     slice_gpu = sl.cpu().numpy().reshape(H, W)
-    scene.free()
     vol.free()
+    lin = photon.volume_load_nrrd(call.density_grad_filename, 1)         # the reference's executed sampler, same slice
+    sl.zero_()
+    scene.trace(sl.data_ptr(), lin, 2, 0, 20)
+    torch.cuda.synchronize()
+    slice_gpu_linear = sl.cpu().numpy().reshape(H, W)
+    lin.free()
+    scene.free()
     del img, sl
     torch.cuda.empty_cache()
     abi = photon.render(call)                                          # the reference's entry point, two launches
@@ -1176,6 +1189,9 @@ def test_c4_whole_job_on_one_gpu(photon, oracle, workdir, monkeypatch):
     ref, ost = oracle.render(head, interpolation=2)
     assert ost.rk_iterations >= 509 * head.num_rays
     assert rel_l2(slice_gpu, ref) <= IMAGE_TOL
+    ref, ost = oracle.render(head, interpolation=1)                      # trilinear, 8-bit weights (.cu:3330, .h:992-1181)
+    assert ost.rk_iterations >= 509 * head.num_rays
+    assert ref.any() and rel_l2(slice_gpu_linear, ref) <= IMAGE_TOL
 
 
 @pytest.mark.parametrize("case", ["piv", "bos_im1", "bos_im2"])
