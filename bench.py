@@ -441,6 +441,30 @@ def check_against_oracle(lib, make_call, vol_path, interp):
     return {"rel_l2": float(np.linalg.norm(g - c) / np.linalg.norm(c)), "sources": 40}
 
 
+def digest(out: dict) -> dict:
+    """The default-path numbers and the stricter roofline figures, short, as the LAST key of the line (a reader that keeps only
+    the tail of the line still gets them).  Times in ms; *_share = (whole job / 8) / an eighth's time on this GPU."""
+    o = out.get("gpu_other_configs") or {}
+    r = out.get("roofline") or {}
+
+    def leg(name, key):
+        v = (o.get(name) or {}).get(key)
+        return round(v, 4) if isinstance(v, float) else v
+    d = {"c3_ms": out.get("ms_per_step"), "c3_kernel_ms": r.get("kernel_ms"), "clock_mhz": r.get("clock_mhz"),
+         "c3_trilinear_ms": leg("C3_trilinear", "ms"), "c3_trilinear_kernel_ms": leg("C3_trilinear", "kernel_ms"),
+         "c3_eighth_share": leg("C3_eighth", "share_of_whole"), "c3_trilinear_eighth_share": leg("C3_trilinear_eighth", "share_of_whole"),
+         "c4_ms": leg("C4", "ms"), "c4_eighth_share": leg("C4_eighth", "share_of_whole"),
+         "c5_ms": leg("C5", "ms"), "c5_eighth_share": leg("C5_eighth", "share_of_whole"),
+         "c2_ms": leg("C2", "ms"), "c2_atomics_per_s": leg("C2", "atomics_per_s"),
+         "piv_sample_ms": leg("PIV_sample", "ms"),
+         "rk45_ms": leg("C3_rk45", "ms"), "adams_bashforth_ms": leg("C3_adams_bashforth", "ms"),
+         "abi_call_ms": (out.get("abi_call") or {}).get("ms"),
+         "devices8_over_single": (out.get("abi_call_devices8_same_gpu") or {}).get("over_single_call"),
+         "frac": r.get("frac"), "frac_vs_nominal_issue": r.get("frac_vs_nominal_issue"), "valu_f32_frac": r.get("valu_f32_frac"),
+         "hbm_frac": r.get("hbm_frac"), "cpu_mrays": round((out.get("cpu_baseline") or {}).get("value") or 0.0, 4) or None}
+    return {k: v for k, v in d.items() if v is not None}
+
+
 # --------------------------------------------------------------------------------------------------
 # one rank
 # --------------------------------------------------------------------------------------------------
@@ -663,7 +687,7 @@ def main():
     # HBM the fraction is ~16, and the measured HBM traffic is <1 % of the peak.  The kernel is bound by how fast its
     # instruction stream ISSUES (measured: SQ_INSTS_VALU per launch, this run's kernel time and the clock the march stamped for
     # itself, against the 2.17 cycles per instruction a stream of independent FMAs reaches) under the board's power cap, which
-    # sets that clock.  Top level = that bound; `texel_rate_vs_lds` keeps the SURVEY 8d figure against the LDS read roof.
+    # sets that clock.  Top level = that bound; `algorithmic_texel_rate` keeps the SURVEY 8d figure as a rate.
     peak_at_clock = LDS_BYTES_PER_CLK * clock_mhz * 1e6 * 1e-9 if clock_mhz > 0 else None       # GB/s
     roofline = {"bound": "valu_issue+power", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
                 "kernel": f"march_kernel<{'rk4' if args.algorithm == 2 else 'euler'},{args.interp}>", "kernel_ms": round(march_ms_avg, 3),
@@ -672,13 +696,16 @@ def main():
                 "wave_generations": round(rays_rank / 64 / (256 * 4 * 5), 2),
                 "board_power": power_w,
                 "march_profile": march_profile, "clock_trace": clock_trace,
-                "valu_issue": None, "lds_pipe": None,
-                "texel_rate_vs_lds": {"what": "SURVEY 8d algorithmic bytes / kernel time against the LDS broadcast-read roof (256 B/clk/CU)",
-                                      "achieved": round(texel_gbs, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(texel_gbs / LDS_PEAK_GBS, 4),
-                                      "peak_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
-                                      "frac_at_clock": round(texel_gbs / peak_at_clock, 4) if peak_at_clock else None,
-                                      "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
-                                      "sensor_taps_per_ray": round(a_bar, 2), "rays_per_launch": rays_rank},
+                "valu_issue": None, "lds_pipe": None, "frac_vs_nominal_issue": None,
+                "valu_f32_frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "hbm_frac": None,
+                # SURVEY 8d's algorithmic bytes over the kernel time: a RATE, not a fraction of any pipe -- a wave fetches a texel block
+                # once, parks it in LDS, and since round 5 three of four z-slabs reach the lanes through DPP from a neighbour's register
+                "algorithmic_texel_rate": {"what": "SURVEY 8d algorithmic bytes (S x 3 x T x 16 B per ray) / kernel time; texels are served from LDS tiles "
+                                                   "and lane registers (DPP), so this is priced against no pipe -- for scale: the LDS read roof is 256 B/clk/CU",
+                                           "achieved": round(texel_gbs, 1), "unit": "GB/s",
+                                           "lds_read_roof_at_clock": round(peak_at_clock, 1) if peak_at_clock else None,
+                                           "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "rk_iterations_per_ray": round(s_bar, 2),
+                                           "sensor_taps_per_ray": round(a_bar, 2), "rays_per_launch": rays_rank},
                 "valu_f32": {"achieved": round(tflops, 2), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 4), "flops_per_sample": flops_per_sample},
                 "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "compulsory_bytes": compulsory, "traffic": None,
@@ -689,7 +716,7 @@ def main():
                         "(SQ_INSTS_VALU measured in this run / kernel time), peak = what the chip's 1024 SIMDs issue at the clock the march "
                         "measured for itself and the 2.17 cycles per instruction of independent FMAs; board_power says how close the "
                         "kernel runs to the cap that sets that clock.  SURVEY 8d's algorithmic bytes are texel bytes served from LDS and "
-                        "lane registers: texel_rate_vs_lds prices them against the LDS read roof, lds_pipe counts the bytes that "
+                        "lane registers: algorithmic_texel_rate is their rate (no single pipe carries them), lds_pipe counts the bytes that "
                         "really pass the LDS pipe; HBM sees the ray state and the touched texels only (hbm.traffic, measured)"}
     out = None
     if rank == 0:
@@ -707,7 +734,7 @@ def main():
             if traffic and kernel_s > 0:
                 gbs = traffic / kernel_s * 1e-9
                 roofline["hbm"]["traffic_gbs"] = round(gbs, 1)
-                roofline["hbm"]["frac"] = round(gbs / HBM_PEAK_GBS, 4)
+                roofline["hbm"]["frac"] = roofline["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
             if insts and clock_mhz > 0 and wave_samples > 0 and kernel_s > 0:
                 # instruction counts of ONE launch of this very library and workload (the child runs the same command line),
                 # time and clock of the timed loop above
@@ -720,8 +747,8 @@ def main():
                 # the same rate against the guide's NOMINAL issue rate: one wave64 VALU instruction per 2 cycles and SIMD at the
                 # 2.4 GHz maximum clock (no measured yardstick, no measured clock in the denominator)
                 nominal = SIMDS * 2.4e9 / 2.0 * 1e-9
-                roofline["frac_vs_nominal_issue"] = {"peak": round(nominal, 1), "frac": round(roofline["achieved"] / nominal, 4),
-                                                     "what": "achieved / (1024 SIMDs x 2.4 GHz / 2 cycles per instruction)"}
+                roofline["frac_vs_nominal_issue"] = round(roofline["achieved"] / nominal, 4)       # achieved / (1024 SIMDs x 2.4 GHz / 2 cycles)
+                roofline["nominal_issue_peak"] = round(nominal, 1)
                 roofline["valu_issue"] = {"valu_per_wave_sample": round(n_valu / wave_samples, 1), "salu_per_wave_sample": round(n_salu / wave_samples, 1),
                                           "lds_per_wave_sample": round(n_lds / wave_samples, 2), "SQ_INSTS_VALU": n_valu,
                                           "cycles_per_inst": round(cyc, 3), "practical_cycles_per_inst": VALU_PRACTICAL_CYCLES_PER_INST,
@@ -733,10 +760,11 @@ def main():
                                         "frac_at_clock": round(lds_gbs / peak_at_clock, 4) if peak_at_clock else None,
                                         "what": "bytes that really pass the LDS pipe: SQ_INSTS_LDS x 1 KiB per wave instruction / kernel time"}
         if roofline["achieved"] is None:
-            # no counter pass in this run (N > 1, --no-traffic, a child run): the top level falls back to SURVEY 8d's texel rate
-            t = roofline["texel_rate_vs_lds"]
-            roofline.update({"bound": "lds (texel delivery; instruction counts not measured in this run)", "achieved": t["achieved"],
-                             "peak": t["peak"], "unit": "GB/s", "frac": t["frac"]})
+            # no counter pass in this run (N > 1, --no-traffic, a child run): the top level falls back to SURVEY 8d's algorithmic
+            # flops against the f32 vector peak of the guide
+            t = roofline["valu_f32"]
+            roofline.update({"bound": "valu_f32 (algorithmic flops; instruction counts not measured in this run)", "achieved": t["achieved"],
+                             "peak": t["peak"], "unit": "TFLOP/s", "frac": t["frac"]})
         others = None
         if world == 1 and not child and not args.no_other_configs:
             is_c3 = args.dots == 200 and args.volume == 256 and interp == 2 and args.algorithm == 2 and args.rays_per_source == 500
@@ -798,6 +826,7 @@ def main():
             out.setdefault("check", {})["sharded_vs_single_gpu_rel_l2"] = float(diff.item())
             out["check"]["what"] = ("rel_l2: this library vs the CPU oracle (40 sources through start_ray_tracing; in a rehearsal the whole job); "
                                     "sharded_vs_single_gpu_rel_l2: the image all ranks reduced onto rank 0 vs the whole job rendered by rank 0's GPU alone")
+        out["digest"] = digest(out)                     # LAST key: what a reader of the line's tail needs (<= 700 characters)
         print(json.dumps(out), flush=True)
     scene.free()
     volume.free()

@@ -252,7 +252,9 @@ int photon_scene_create(float lens_pitch, float image_distance,
                         photon_scene_t **out);
 /* Waits for the scene's device first when a trace of this scene may still be running (its device blocks go back to the
  * library's block cache, see photon_trim_caches, and may be handed to the next scene at once): freeing a scene right after an
- * asynchronous photon_trace is safe on any stream. */
+ * asynchronous photon_trace is safe on any stream.  A scene belongs to the device that was current when it was created;
+ * photon_trace, photon_scene_free and the statistics calls make that device current for their duration and restore the
+ * caller's, so they may be called with any device current. */
 void photon_scene_free(photon_scene_t *scene);
 
 /* Noise hooks of start_ray_tracing (its add_pos_noise / pos_noise_std / add_ngrad_noise /

@@ -101,6 +101,8 @@ struct photon_scene {
                                         // hand-off error count (scene_error_word), so whatever zeroes the statistics zeroes it too
     unsigned *d_queue = nullptr;        // the march's work queues: room for 64 counters a cache line apart, 8 XCDs x kSubQueues (4) in use + the
                                         // ticket of the waves that have left; zeroed at creation, re-armed by every launch's last wave
+    int device = 0;                     // the device the scene was created on: every entry point that launches, allocates, frees or waits
+                                        // for this scene makes it current first (DeviceScope) and hands the caller's device back
     int num_cus = 256;                  // compute units of the scene's device (size of the persistent march grid)
     unsigned march_epoch = 0;           // tag of the last segmented march launch in ws.seg_flag
     int march_segments = -1;            // photon_scene_set_march_segments: -1 the library's choice, 1 whole marches, n segments
@@ -132,6 +134,18 @@ struct photon_scene {
 };
 
 namespace photon {
+
+// Makes `device` current for the scope and restores the caller's device afterwards (no HIP call at all when it already is).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 // rays per launch: bounded so that 32-bit ray ids suffice and the state stays a few GB
 constexpr unsigned kMaxRaysPerLaunch = 1u << 26;

@@ -281,7 +281,10 @@ extern "C" int photon_trace_volume_rays_queued(const photon_volume_t *vol, int r
         } } cleanup{&sc};
         sc.march_segments = segments;
         int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) sc.num_cus = cus;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            sc.device = dev;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) sc.num_cus = cus;
+        }
         PH_CHECK(pool_malloc((void **)&sc.d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
         PH_CHECK(device_zero(sc.d_counters, (size_t)kCounterSlots * kCounterStride * sizeof(unsigned long long)));
         PH_CHECK(pool_malloc((void **)&sc.d_queue, kQueues * kQueueStride * sizeof(unsigned)));
@@ -313,6 +316,7 @@ extern "C" int photon_scene_set_march_segments(photon_scene_t *scene, int segmen
 extern "C" int photon_scene_set_march_profile(photon_scene_t *scene, int on) {
     if (!scene) return 1;
     return guarded("photon_scene_set_march_profile", [&]() -> int {
+        DeviceScope on_scene_device(scene->device);
         if (on && !scene->d_profile) {
             PH_CHECK(pool_malloc((void **)&scene->d_profile, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));
             PH_CHECK(device_zero(scene->d_profile, (size_t)kProfileLaunches * kProfileSub * PF_N * sizeof(unsigned long long)));

@@ -167,6 +167,7 @@ void photon_scene_free(photon_scene_t *s) {
     // The blocks below go back to the CACHE, not to the runtime (whose hipFree would wait for the device): the next scene of
     // the same shape may be handed them at once and overwrite them with copies on the null stream, which does not wait for
     // kernels of this scene still running on a non-blocking stream.  So wait here; microseconds on an idle device.
+    photon::DeviceScope on_scene_device(s->device);             // the caller may have another device current: wait on, and free into, the scene's
     scene_quiesce(s);
     for (void *p : s->allocs) pool_free(p);
     pool_free(s->ws.px);
@@ -522,8 +523,10 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     {
         int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            s->num_cus = cus;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            s->device = dev;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) s->num_cus = cus;
+        }
     }
     for (auto &ev : s->ev) {
         e = hipEventCreate(&ev);
@@ -578,6 +581,7 @@ namespace photon {
 
 void scene_quiesce(photon_scene *s) {
     if (!s->launched) return;
+    DeviceScope on_scene_device(s->device);                     // hipDeviceSynchronize waits for the CURRENT device
     (void)hipDeviceSynchronize();
     s->launched = false;
 }

@@ -108,6 +108,7 @@ namespace photon {
 
 int begin_accumulate(photon_scene *s, hipStream_t stream) {
     const size_t npix = (size_t)s->dev.cam.x_pixel_number * s->dev.cam.y_pixel_number;
+    s->launched = true;                                     // the fill and, later, the finalize kernel use d_acc even when no source is traced
     if (!s->acc_clean) PH_CHECK(hipMemsetAsync(s->d_acc, 0, npix * sizeof(double), stream));      // else: left zeroed by the last finalize
     s->acc_clean = false;
     return 0;
@@ -256,6 +257,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
         return 1;
     }
     return guarded("photon_trace", [&]() -> int {
+        photon::DeviceScope on_scene_device(scene->device);
         hipStream_t stream = (hipStream_t)stream_p;
         const unsigned rps = (unsigned)scene->dev.rays_per_source;
         size_t w0 = 0, w1 = 0;
@@ -299,6 +301,7 @@ extern "C" int photon_trace(photon_scene_t *scene, const photon_volume_t *vol, i
 extern "C" int photon_scene_stats_begin(photon_scene_t *scene, void *stream_p) {
     if (!scene) return 1;
     return guarded("photon_scene_stats_begin", [&]() -> int {
+        photon::DeviceScope on_scene_device(scene->device);
         hipStream_t stream = (hipStream_t)stream_p;
         PH_CHECK(hipMemsetAsync(scene->d_counters, 0, kCounterBytes, stream));
         { const int rc = profile_reset(scene, stream); if (rc) return rc; }
@@ -326,6 +329,7 @@ extern "C" int photon_scene_stats_end(photon_scene_t *scene, void *stream_p, pho
         return 1;
     }
     return guarded("photon_scene_stats_end", [&]() -> int {
+        photon::DeviceScope on_scene_device(scene->device);
         scene->win_open = false;
         PH_CHECK(hipStreamSynchronize((hipStream_t)stream_p));
         memset(stats, 0, sizeof *stats);

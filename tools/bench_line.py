@@ -8,9 +8,9 @@ for path in sys.argv[1:]:
             continue
         d = json.loads(ln)
         r = d["roofline"]
-        t = r.get("texel_rate_vs_lds") or r                      # lines written before round 4 carry these at the top level
+        t = r.get("algorithmic_texel_rate") or r.get("texel_rate_vs_lds") or r      # (round-4/5 name; before round 4 at the top level)
         p = r.get("march_profile") or {}
         print(path, "Mrays/s", d["value"], "ms/step", d["ms_per_step"], "march_ms", r["kernel_ms"], "clock_mhz", r.get("clock_mhz"),
-              "texel_frac", t.get("frac"), "at_clock", t.get("frac_at_clock"), "wave_ms", r.get("wave_lifetime_ms"),
+              "issue_frac", r.get("frac"), "texel_GBs", t.get("achieved"), "wave_ms", r.get("wave_lifetime_ms"),
               "gens", r.get("wave_generations"), "span/drain_ms", p.get("span_ms"), p.get("drain_ms"),
               "power_w", (r.get("board_power") or {}).get("median_w"), "check", d.get("check"))
