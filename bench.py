@@ -350,9 +350,16 @@ def gpu_other_configs(lib, torch, workdir, with_c4, headline):
             leg["atomics_per_s"] = round(st.sensor_taps / reps / dt, 1)
             leg["atomics_what"] = ("algorithmic: the reference issues one atomicAdd per tap (parallel_ray_tracing.cu:2223-2233); the "
                                    "wave-cooperative splat sums a wave's taps per pixel in f64 first and issues one atomic per pixel and wave")
-            leg["lens_samples_launched"] = {"per_source": scene.live_rays(), "of": int(call.lightray_number_per_particle),
-                                            "what": "rays counts sources x rays per source, as requested; the lens samples that cannot reach the "
-                                                    "first element's aperture from any source are not launched (same image bit for bit)"}
+            kept = scene.live_sources()
+            n_src_launched = call.num_sources if kept is None else int(kept.size)
+            launched = n_src_launched * scene.live_rays()
+            leg["rays_launched"] = launched
+            leg["Mrays_launched_per_s"] = round(launched / dt * 1e-6, 1)
+            leg["launched"] = {"lens_samples_per_source": scene.live_rays(), "of": int(call.lightray_number_per_particle),
+                               "sources": n_src_launched, "of_sources": call.num_sources,
+                               "what": "rays / Mrays_per_s count sources x rays per source AS REQUESTED (what the reference traces); not launched: the "
+                                       "lens samples that cannot reach the first element's aperture from any source, and the sources whose image "
+                                       "cannot fall on the sensor (same image bit for bit) -- Mrays_launched_per_s is the rate over the rest"}
         if whole is not None:
             whole_ms, whole_kernel_ms = whole
             leg["share_of_whole"] = round(whole_ms / 8.0 / (dt * 1e3), 4)
@@ -366,6 +373,12 @@ def gpu_other_configs(lib, torch, workdir, with_c4, headline):
 
     vol256 = os.path.join(workdir, "bos_256.nrrd")
     run("C2", scenes.config("C2"), 0, "PIV, 100 particles x 1e4 rays, Mie, thick lens, 4-pixel splat, no volume (one fused kernel)", reps=200)
+    piv_json = os.path.join(scenes.GOLDEN_DIR, "abi_piv_full.json")
+    if os.path.exists(piv_json):
+        # photon's own sample PIV frame at its real size (inputs captured from the reference's driver): 50 000 particles x 10 000 rays
+        from photon_amd.ray_tracing import RayTracingCall
+        piv = RayTracingCall.from_fixture(piv_json, piv_json[:-5] + ".npz", density_dir=scenes.GOLDEN_DIR)
+        run("PIV_sample", piv, 0, "sample-data/piv at full size: 5e4 particles x 1e4 rays = 5e8 rays, Mie, thick lens, 4-pixel splat, no volume", reps=5)
     lin = run("C3_trilinear", scenes.config("C3", workdir), 1,
               "the headline job with the trilinear sampler and the texture unit's 8-bit weights (the reference's executed path)", reps=10)
     eighth = scenes.bos_scene(n_dots=25, density_grad_filename=vol256)

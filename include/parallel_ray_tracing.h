@@ -336,6 +336,21 @@ int photon_scene_set_skip_doomed(photon_scene_t *scene, int on);
 int photon_scene_live_rays(const photon_scene_t *scene);
 /* the kept lens samples themselves, ascending (out: room for `capacity` >= photon_scene_live_rays entries); returns their number, -1 on a bad argument */
 int photon_scene_live_samples(const photon_scene_t *scene, int *out, int capacity);
+/* The same switch also leaves out, on the volume-free path, the SOURCES whose image cannot fall on the sensor (one biconvex
+ * thick lens on the axis, host source arrays, no sensor-position noise, no dumps: photon_scene.hip, source_misses_sensor --
+ * an interval bound on where the lens can put the source's rays; photon's sample PIV frame draws particles over a field 1.5 x
+ * wider than the camera sees, run_simulation_02.py:956-958).  The image is unchanged.  photon_scene_live_sources: the sources
+ * that are launched, ascending (out may be NULL to ask for the count); -1 when nothing could be ruled out (all are), -2 on a
+ * bad argument. */
+long long photon_scene_live_sources(const photon_scene_t *scene, int *out, long long capacity);
+/* The bound itself, host arithmetic only (no device call, usable without a GPU): off[i] = 1 when source (x, y, z)[i] cannot
+ * reach a pixel through any of the lens samples (lens_x, lens_y)[k] on the plane z = image_distance.  Returns 0; 1 when the
+ * geometry is not covered (off all zeros); 2 on a bad argument. */
+int photon_sources_missing_sensor(const float *lens_x, const float *lens_y, int n_samples, float image_distance, float beam_wavelength,
+                                  int num_elements, const element_data_t *element_data_p, const double (*element_center)[3],
+                                  const double (*element_plane_parameters)[4], const int *element_system_index,
+                                  const camera_design_t *camera_design_p, const float *x, const float *y, const float *z,
+                                  long long n, unsigned char *off);
 
 /* The launch loop (parallel_ray_tracing.cu:3515-3672) for sources [src_begin, src_end)
  * with everything resident in HBM.  d_image: device f32[H*W], accumulated into.

@@ -69,6 +69,8 @@ struct SceneDev {
     int slot_rays;
     const int *slot_map;
     const int *src_perm;                // spatial order of THIS launch's sources (lens-major only); nullptr = identity
+    const int *src_list;                // source-major, volume-free path: the launch's sources that can reach the sensor (already offset
+                                        // to the launch's first one); nullptr = every source of [src_begin, src_end)
     // index of this scene's source 0 in the caller's source list (PHOTON_DEVICES uploads each device only its
     // shard): keeps the noise generator's per-ray key independent of the sharding
     long long source_base;
@@ -82,7 +84,7 @@ __device__ __forceinline__ void slot_to_ray(const SceneDev &sc, long long src_be
                                             int &local_ray) {
     const unsigned rps = (unsigned)sc.slot_rays;
     if (sc.ray_order == 0) {
-        source = (int)(src_begin + r / rps);
+        source = sc.src_list ? sc.src_list[r / rps] : (int)(src_begin + r / rps);
         local_ray = (int)(r % rps);
     } else {
         const unsigned n_src = n_rays / rps;

@@ -128,6 +128,9 @@ struct photon_scene {
     const int *d_live = nullptr;        // the lens samples that can reach element 0's aperture from ANY source of this scene, ascending
     int live_count = 0;                 // (part of the upload block); == rays_per_source when none can be ruled out (or nothing is known)
     std::vector<int> live_host;         // the same list on the host (photon_scene_live_samples: tests hold the bound against exact geometry)
+    const int *d_live_sources = nullptr;    // the sources whose image can fall on the sensor (photon_scene.hip, source_misses_sensor), ascending;
+    std::vector<int> live_sources;      // part of the upload block, and the same list on the host; used by the volume-free path only
+    bool live_sources_known = false;    // false: nothing could be ruled out (or the geometry is not covered): every source is launched
     PermEntry perms[4];                 // spatial (Morton) orders of the lens-major launch ranges seen last
     unsigned long long perm_clock = 0;
     photon_sort_scratch sort_scratch;   // keys / indices / radix-sort temporaries, grown on demand (photon_sort.hip)

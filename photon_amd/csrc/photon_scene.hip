@@ -320,7 +320,9 @@ static std::vector<int> live_lens_samples(const std::vector<float> &lx, const st
     const char type = edp[0].element_type;
     const double pitch = edp[0].element_geometry.pitch;
     if ((type != 'l' && type != 't') || !(pitch > 0)) return all;
-    if (plane[0][0] != 0.0 || plane[0][1] != 0.0 || plane[0][2] == 0.0 || center[0][0] != 0.0 || center[0][1] != 0.0) return all;
+    // (the dz bound below puts the front vertex on the +z side of the centre: plane normal c > 0, what the reference's Python always
+    // emits, perform_ray_tracing_03.py:49; a flipped normal moves the front sphere, .cu:557 -- leave that to the kernels)
+    if (plane[0][0] != 0.0 || plane[0][1] != 0.0 || !(plane[0][2] > 0.0) || center[0][0] != 0.0 || center[0][1] != 0.0) return all;
     const double za = image_distance;
     double dz;
     if (type == 't') {
@@ -352,6 +354,138 @@ static std::vector<int> live_lens_samples(const std::vector<float> &lx, const st
     if (live.empty()) live.push_back(0);                                // a launch of zero rays per source is nobody's friend
     return live;
 }
+
+// The sources whose image CANNOT fall on the sensor, whatever lens sample the ray is aimed at: they need not be launched on the
+// volume-free path.  photon's sample PIV frame draws its particles over a field 1.5 x wider than the camera sees
+// (run_simulation_02.py:956-958): more than half of them image beside the sensor.
+//
+// One biconvex thick lens ('l', on the z axis, normal +z), then the sensor plane z = z_sensor.  Everything a surviving ray
+// does is, in the xy plane, a linear combination of two vectors -- its aim point P on the plane z = image_distance (.cu:123-141)
+// and its source's S = (x_s, y_s) -- with SCALAR coefficients, because the lens is rotationally symmetric and every surface
+// normal's xy part is the hit point's over the radius:
+//     H1 = (1 + e) P - e S                     front hit;  e = (z_H1 - z_a) / (z_a - z_s), z_H1 within the front sag of the vertex
+//     n v = u - a1 H1,   u = q (P - S)         Snell in vector form (.cu:652-682); q = 1 / |P - S| (3-D), a1 = G1 / R1,
+//                                              G1 = n cos(t') - cos(t) = sqrt(n^2 - sin^2 t) - cos t: n - 1 at normal incidence, growing with t
+//     H2 = H1 + s2 v                           back hit; s2 = glass path = (z_H1 - z_H2) / |v_z|
+//     w  = n v - a2 H2                         a2 = G2 / |R2|, G2 = n cos(t) - cos(t') likewise from n - 1 upwards (.cu:797-827)
+//     h  = H2 + tau w                          sensor hit; tau = (z_H2 - z_sensor) / |w_z|
+// so h = A P + B S with A, B polynomials in (e, q, a1, a2, s2, tau).  Each of the six lies in an interval that follows from the
+// aperture tests alone (both hits within pitch / 2 of the axis, .cu:560-566, 737-743: a ray that fails one is dead anyway):
+// sin(incidence) <= |u_xy| + (pitch / 2) / R, the sags of the two caps, |v_xy| and |w_xy| from the same sums.  A and B are
+// evaluated in interval arithmetic; |P| <= the largest lens sample, and for a ray that passes the front aperture also
+// <= (pitch / 2 + |e| r_s) / (1 - |e|).  The source is OFF when the box  B S +- |A|max |P|max +- slack  misses the rectangle of
+// sensor hits that reach a pixel (.cu:1440-1452, 1803-1815: half a pixel beyond the array either side; one more pixel here).
+// slack: 10 um + 1e-5 of the ray's length for the kernels' f32 arithmetic (its cancellation in the sphere intersection is worth
+// 1.5 um along the ray, tests/test_oracle_golden.py).  Held against exact f64 ray tracing of every ray of every culled source in
+// tests/test_parity_gpu.py::test_culled_sources_against_exact_geometry; geometries this does not cover keep every source.
+}  // extern "C"  (overloaded helpers below)
+namespace {
+struct Ivl {
+    double lo, hi;
+};
+inline Ivl iv(double a) { return Ivl{a, a}; }
+inline Ivl iv(double a, double b) { return a <= b ? Ivl{a, b} : Ivl{b, a}; }
+inline Ivl operator+(Ivl a, Ivl b) { return Ivl{a.lo + b.lo, a.hi + b.hi}; }
+inline Ivl operator-(Ivl a) { return Ivl{-a.hi, -a.lo}; }
+inline Ivl operator-(Ivl a, Ivl b) { return a + (-b); }
+inline Ivl operator*(Ivl a, Ivl b) {
+    const double c0 = a.lo * b.lo, c1 = a.lo * b.hi, c2 = a.hi * b.lo, c3 = a.hi * b.hi;
+    return Ivl{std::min(std::min(c0, c1), std::min(c2, c3)), std::max(std::max(c0, c1), std::max(c2, c3))};
+}
+inline Ivl operator*(Ivl a, double b) { return a * iv(b); }
+inline double mag(Ivl a) { return std::max(fabs(a.lo), fabs(a.hi)); }
+
+struct LensCull {                       // what does not depend on the source
+    bool ok = false;
+    double za, zf, zb, z_sen, R1, R2a, n, hp, t, sag1, sag2, rp_all, half_x, half_y;
+};
+}  // namespace
+
+static LensCull lens_cull_setup(const std::vector<float> &lx, const std::vector<float> &ly, float image_distance, float beam_wavelength,
+                                int num_elements, const element_data_t *edp, const double (*center)[3], const double (*plane)[4],
+                                const int *sys_index, const camera_design_t *cam) {
+    LensCull c;
+    if (num_elements < 1 || edp[0].element_type != 'l') return c;
+    // the reference's element path sends the ray through element 0 once per single-member group (.cu:1331-1333): exactly once here
+    {
+        const int n = std::min(num_elements, kMaxElements);
+        int seq = 0, applications = 0;
+        for (int k = 0; k < n; k++) seq = std::max(seq, sys_index[k]);
+        for (int idx = 0; idx < seq; idx++) {
+            int count = 0;
+            for (int k = 0; k < n; k++) count += (seq - sys_index[k] == idx);
+            applications += count == 1;
+        }
+        if (applications != 1) return c;
+    }
+    if (plane[0][0] != 0.0 || plane[0][1] != 0.0 || !(plane[0][2] > 0.0) || center[0][0] != 0.0 || center[0][1] != 0.0) return c;
+    const element_data_t &e = edp[0];
+    c.R1 = e.element_geometry.front_surface_radius;
+    c.R2a = -(double)e.element_geometry.back_surface_radius;
+    c.hp = (double)(float)e.element_geometry.pitch / 2.0;                // the kernels compare against the f32 pitch
+    c.t = e.element_geometry.vertex_distance;
+    double n = e.element_properties.refractive_index;
+    const double abbe = (float)e.element_properties.abbe_number;
+    if (abbe == abbe) {                                                 // .cu:622-636: the index at the beam's wavelength
+        const double lD = 589.3, lF = 486.1, lC = 656.3, w = beam_wavelength;
+        n = n + (1.0 / (w * w) - 1.0 / (lD * lD)) * ((n - 1) / (abbe * (1 / (lF * lF) - 1 / (lC * lC))));
+    }
+    c.n = n;
+    if (!(c.R1 > 0) || !(c.R2a > 0) || !(n > 1.0) || !(n < 4.0) || !(c.hp > 0) || !(c.t >= 0)) return c;
+    if (!(c.hp < 0.95 * c.R1) || !(c.hp < 0.95 * c.R2a)) return c;
+    c.za = image_distance;
+    c.zf = center[0][2] + c.t / 2;
+    c.zb = center[0][2] - c.t / 2;
+    c.z_sen = cam->z_sensor;
+    c.sag1 = c.R1 - sqrt(c.R1 * c.R1 - c.hp * c.hp);
+    c.sag2 = c.R2a - sqrt(c.R2a * c.R2a - c.hp * c.hp);
+    if (!(c.zb > c.z_sen) || !(cam->pixel_pitch > 0)) return c;
+    double rp = 0;
+    for (size_t k = 0; k < lx.size(); k++) rp = std::max(rp, sqrt((double)lx[k] * lx[k] + (double)ly[k] * ly[k]));
+    c.rp_all = rp * (1 + 1e-6);
+    c.half_x = (double)cam->pixel_pitch * (cam->x_pixel_number + 1) / 2.0 + cam->pixel_pitch;
+    c.half_y = (double)cam->pixel_pitch * (cam->y_pixel_number + 1) / 2.0 + cam->pixel_pitch;
+    c.ok = c.za == c.za && c.zf == c.zf && c.half_x == c.half_x && c.half_y == c.half_y;
+    return c;
+}
+
+// true: no ray of the source (xs, ys, zs) that passes both apertures of the lens can reach a pixel
+static bool source_misses_sensor(const LensCull &c, double xs, double ys, double zs) {
+    const double Ds = zs - c.za;
+    if (!(Ds > 0) || !(zs > c.zf + (c.zf - c.zb))) return false;
+    const double rs = sqrt(xs * xs + ys * ys);
+    if (!(rs == rs)) return false;
+    const Ivl e = iv(-(c.zf - c.za) / Ds, -(c.zf - c.sag1 - c.za) / Ds);
+    const double em = mag(e);
+    if (!(em < 0.25)) return false;
+    const double rp = std::min(c.rp_all, (c.hp + em * rs) / (1 - em));
+    const double gmax = rs + rp, gmin = std::max(0.0, rs - rp);
+    const double lmax = sqrt(gmax * gmax + Ds * Ds);
+    const Ivl q = iv(1.0 / lmax, 1.0 / sqrt(gmin * gmin + Ds * Ds));
+    const double su = gmax / lmax;                                      // |u_xy| at most
+    const double s1 = su + c.hp / c.R1;                                 // sin(incidence at the front) at most
+    if (!(s1 < 0.9)) return false;
+    const Ivl a1 = iv(c.n - 1, sqrt(c.n * c.n - s1 * s1) - sqrt(1 - s1 * s1)) * (1.0 / c.R1);
+    const double sv = (su + a1.hi * c.hp) / c.n;                        // |v_xy| at most
+    const double s2m = sv + c.hp / c.R2a;                               // sin(incidence at the back, in the glass) at most
+    if (!(c.n * s2m < 0.9)) return false;
+    const Ivl a2 = iv(c.n - 1, sqrt(c.n * c.n - c.n * c.n * s2m * s2m) - sqrt(1 - c.n * c.n * s2m * s2m)) * (1.0 / c.R2a);
+    const Ivl s2 = iv(std::max(0.0, c.t - c.sag1 - c.sag2), c.t / sqrt(1 - sv * sv));
+    const double sw = c.n * sv + a2.hi * c.hp;                          // |w_xy| at most
+    if (!(sw < 0.9)) return false;
+    const Ivl tau = iv(c.zb - c.z_sen, (c.zb + c.sag2 - c.z_sen) / sqrt(1 - sw * sw));
+    const Ivl one_e = iv(1.0) + e;
+    const Ivl cP = q - a1 * one_e, cS = a1 * e - q;                     // n v = cP P + cS S
+    const Ivl hP = one_e + s2 * cP * (1.0 / c.n), hS = s2 * cS * (1.0 / c.n) - e;      // H2 = hP P + hS S
+    const Ivl k = iv(1.0) - tau * a2;
+    const Ivl A = k * hP + tau * cP, B = k * hS + tau * cS;
+    const double blur = mag(A) * rp + 1e-5 * (Ds + tau.hi) + 10.0;
+    if (!(blur == blur)) return false;
+    const Ivl bx = B * xs, by = B * ys;
+    return bx.lo - blur > c.half_x || bx.hi + blur < -c.half_x || by.lo - blur > c.half_y || by.hi + blur < -c.half_y;
+}
+
+extern "C" {
 
 static int scene_create_impl(float lens_pitch, float image_distance, const scattering_data_t *sdp,
                              const char *scattering_type_str, const lightfield_source_t *lsp,
@@ -475,6 +609,24 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         s->live_count = (int)live.size();
         s->live_host = live;
         if (live.size() < lx.size() && (rc = upload(s, pack, live.data(), live.size(), &s->d_live))) return bail(rc);
+        // ... and which SOURCES can reach the sensor at all (source_misses_sensor above), from the caller's arrays
+        s->live_sources_known = false;
+        if (!generated && ns > 0 && lx.size() >= 2) {
+            const LensCull cull = lens_cull_setup(lx, ly, image_distance, beam_wavelength, num_elements, edp, element_center,
+                                                  element_plane_parameters, element_system_index, cam);
+            if (cull.ok) {
+                std::vector<int> keep;
+                keep.reserve(ns);
+                for (size_t i = 0; i < ns; i++)
+                    if (!source_misses_sensor(cull, lsp->x[i], lsp->y[i], lsp->z[i])) keep.push_back((int)i);
+                if (keep.size() < ns) {
+                    if (keep.empty()) keep.push_back(0);                // a launch of zero rays is nobody's friend
+                    if ((rc = upload(s, pack, keep.data(), keep.size(), &s->d_live_sources))) return bail(rc);
+                    s->live_sources = std::move(keep);
+                    s->live_sources_known = true;
+                }
+            }
+        }
     }
     d.num_elements = num_elements;
     {
@@ -567,6 +719,36 @@ int photon_scene_live_samples(const photon_scene_t *s, int *out, int capacity) {
     if (!s || !out || capacity < s->live_count) return -1;
     for (int k = 0; k < s->live_count; k++) out[k] = s->live_host[(size_t)k];
     return s->live_count;
+}
+
+// The bound behind photon_scene_live_sources on its own, host only (no device call): off[i] = 1 when source i cannot reach the
+// sensor through lens samples (lens_x[k], lens_y[k]).  Returns 0, or 1 when the geometry is not covered (off is all zeros).
+int photon_sources_missing_sensor(const float *lens_x, const float *lens_y, int n_samples, float image_distance, float beam_wavelength,
+                                  int num_elements, const element_data_t *edp, const double (*element_center)[3],
+                                  const double (*element_plane_parameters)[4], const int *element_system_index,
+                                  const camera_design_t *cam, const float *x, const float *y, const float *z, long long n,
+                                  unsigned char *off) {
+    if (!lens_x || !lens_y || n_samples < 1 || !edp || !element_center || !element_plane_parameters || !element_system_index || !cam ||
+        n < 0 || (n > 0 && (!x || !y || !z || !off))) return 2;
+    for (long long i = 0; i < n; i++) off[i] = 0;
+    const std::vector<float> lx(lens_x, lens_x + n_samples), ly(lens_y, lens_y + n_samples);
+    const LensCull cull = lens_cull_setup(lx, ly, image_distance, beam_wavelength, num_elements, edp, element_center,
+                                          element_plane_parameters, element_system_index, cam);
+    if (!cull.ok) return 1;
+    for (long long i = 0; i < n; i++) off[i] = source_misses_sensor(cull, x[i], y[i], z[i]) ? 1 : 0;
+    return 0;
+}
+
+// The sources the volume-free path launches (ascending indices), or -1 when every source is (nothing could be ruled out)
+long long photon_scene_live_sources(const photon_scene_t *s, int *out, long long capacity) {
+    if (!s) return -2;
+    if (!s->live_sources_known) return -1;
+    const long long n = (long long)s->live_sources.size();
+    if (out) {
+        if (capacity < n) return -2;
+        memcpy(out, s->live_sources.data(), (size_t)n * sizeof(int));
+    }
+    return n;
 }
 
 int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {

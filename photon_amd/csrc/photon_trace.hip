@@ -114,15 +114,33 @@ int begin_accumulate(photon_scene *s, hipStream_t stream) {
     return 0;
 }
 
+// Without a volume only the lens samples that can reach the first aperture are launched (photon_scene.hip, live_lens_samples):
+// the dead ones would be generated, meet the element's front surface and be dropped -- half of a full-aperture PIV cone.
+static bool launches_live_samples_only(const photon_scene *s, const photon_volume *vol, const DumpDev &dump) {
+    return !vol && s->skip_doomed && s->d_live && s->live_count < s->dev.rays_per_source && !dump.final_pos && !dump.inter_pos &&
+           first_aperture_applies(s);
+}
+// ... and only the sources whose image can fall on the sensor (photon_scene.hip, source_misses_sensor): same conditions, no
+// sensor-position noise (unbounded), the scene's source list as it was created
+static bool launches_live_sources_only(const photon_scene *s, const photon_volume *vol, const DumpDev &dump) {
+    return !vol && s->skip_doomed && s->live_sources_known && !dump.final_pos && !dump.inter_pos && !s->dev.noise.add_pos &&
+           first_aperture_applies(s);
+}
+
 int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
                         long long src_end, DumpDev dump, hipStream_t stream, hipEvent_t ev_march_begin, hipEvent_t ev_march_end) {
-    // Without a volume only the lens samples that can reach the first aperture are launched (photon_scene.hip, live_lens_samples):
-    // the dead ones would be generated, meet the element's front surface and be dropped -- half of a full-aperture PIV cone.
-    const bool live_only = !vol && s->skip_doomed && s->d_live && s->live_count < s->dev.rays_per_source && !dump.final_pos &&
-                           !dump.inter_pos && first_aperture_applies(s);
+    const bool live_only = launches_live_samples_only(s, vol, dump);
     s->dev.slot_rays = live_only ? s->live_count : s->dev.rays_per_source;
     s->dev.slot_map = live_only ? s->d_live : nullptr;
-    const unsigned long long n64 = (unsigned long long)(src_end - src_begin) * (unsigned)s->dev.slot_rays;
+    s->dev.src_list = nullptr;
+    long long n_sources = src_end - src_begin;
+    if (launches_live_sources_only(s, vol, dump)) {
+        const auto lo = std::lower_bound(s->live_sources.begin(), s->live_sources.end(), (int)src_begin);
+        const auto hi = std::lower_bound(lo, s->live_sources.end(), (int)src_end);
+        n_sources = hi - lo;
+        s->dev.src_list = s->d_live_sources + (lo - s->live_sources.begin());
+    }
+    const unsigned long long n64 = (unsigned long long)n_sources * (unsigned)s->dev.slot_rays;
     if (n64 == 0) return 0;
     if (n64 > kMaxRaysPerLaunch) {
         fprintf(stderr, "photon: a launch of %llu rays (sources [%lld, %lld) x %d) exceeds the %u-ray limit per launch\n", n64,
@@ -185,12 +203,23 @@ int trace_accumulate(photon_scene *scene, const photon_volume *vol, int ray_trac
                             long long src_end, hipStream_t stream, int timed, float *march_ms_out) {
     const unsigned rps = (unsigned)scene->dev.rays_per_source;
     if (rps > kMaxRaysPerLaunch) { fprintf(stderr, "photon: too many rays per source\n"); return 1; }
-    const long long max_sources = std::max<long long>(1, kMaxRaysPerLaunch / rps);
     float march_ms = 0.f;
     const DumpDev no_dump{nullptr, nullptr, 0, nullptr, nullptr, 0};
+    // a launch holds at most kMaxRaysPerLaunch rays: of those it really launches (the volume-free path leaves out dead lens samples
+    // and sources that miss the sensor -- the sample PIV frame's 5e8 rays go in two launches, not eight)
+    const unsigned slot_rays = launches_live_samples_only(scene, vol, no_dump) ? (unsigned)scene->live_count : rps;
+    const long long max_sources = std::max<long long>(1, kMaxRaysPerLaunch / slot_rays);
+    const bool listed = launches_live_sources_only(scene, vol, no_dump);
     { const int rc = begin_accumulate(scene, stream); if (rc) return rc; }
-    for (long long b = src_begin; b < src_end; b += max_sources) {
-        const long long e = std::min<long long>(src_end, b + max_sources);
+    for (long long b = src_begin, e = src_begin; b < src_end; b = e) {
+        e = std::min<long long>(src_end, b + max_sources);
+        if (listed) {                                           // up to max_sources LISTED sources: the range ends before the next one
+            const auto &ls = scene->live_sources;
+            const auto lo = std::lower_bound(ls.begin(), ls.end(), (int)b);
+            e = (ls.end() - lo) > max_sources ? (long long)lo[max_sources] : src_end;
+            e = std::min<long long>(e, src_end);
+            if (e <= b) e = src_end;                            // (cannot happen: lo[max_sources] > *lo >= b)
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed == 1 && vol) { e0 = scene->ev[1]; e1 = scene->ev[2]; }
         size_t i0 = 0, i1 = 0;

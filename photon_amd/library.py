@@ -20,7 +20,7 @@ from .ray_tracing import (RayTracingCall, bind_start_ray_tracing, camera_design_
 DECLARED_SYMBOLS = (
     "start_ray_tracing", "photon_set_device", "photon_device_pci_bus_id", "photon_rand_table", "photon_volume_load_nrrd",
     "photon_volume_from_density", "photon_volume_info", "photon_volume_set_weight_bits", "photon_volume_download", "photon_volume_sample",
-    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_live_rays", "photon_scene_live_samples", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_chunk", "photon_march_queue_size",
+    "photon_volume_free", "photon_scene_create", "photon_scene_free", "photon_scene_set_noise", "photon_scene_set_element_train", "photon_scene_set_ray_order", "photon_scene_set_skip_doomed", "photon_scene_live_rays", "photon_scene_live_samples", "photon_scene_live_sources", "photon_sources_missing_sensor", "photon_scene_set_source_base", "photon_march_queue_group", "photon_march_queue_count", "photon_march_queue_chunk", "photon_march_queue_size",
     "photon_scene_set_march_segments", "photon_march_segments_plan", "photon_trim_caches", "photon_trace",
     "photon_scene_stats_begin", "photon_scene_stats_end", "photon_scene_check", "photon_scene_set_march_profile", "photon_scene_march_profile", "photon_scene_march_profile_raw",
     "photon_trace_volume_rays", "photon_trace_volume_rays_queued", "photon_version",
@@ -203,6 +203,26 @@ class PhotonLibrary:
         r2 = np.empty(n, np.float32)
         self._check(self.lib.photon_rand_table(n, _ptr(r1), _ptr(r2)), "photon_rand_table")
         return r1, r2
+
+    def sources_missing_sensor(self, call: RayTracingCall, lens_x, lens_y):
+        """photon_sources_missing_sensor (host arithmetic, no GPU needed): bool[num_sources], True = no ray of that source
+        through any of the given lens samples can reach a pixel; None when the call's geometry is not covered."""
+        sd, ls, elems, centers, planes, sysidx, cam = call.pack()
+        lx = np.ascontiguousarray(lens_x, np.float32)
+        ly = np.ascontiguousarray(lens_y, np.float32)
+        x, y, z = (np.ascontiguousarray(a, np.float32) for a in (call.src_x, call.src_y, call.src_z))
+        off = np.zeros(x.size, np.uint8)
+        f = self.lib.photon_sources_missing_sensor
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p,
+                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_longlong, ctypes.c_void_p]
+        rc = f(_ptr(lx), _ptr(ly), int(lx.size), float(call.image_distance), float(call.beam_wavelength), len(call.elements),
+               ctypes.cast(elems, ctypes.c_void_p), _ptr(centers), _ptr(planes), _ptr(sysidx), ctypes.addressof(cam), _ptr(x), _ptr(y), _ptr(z),
+               int(x.size), _ptr(off))
+        if rc == 1:
+            return None
+        self._check(rc, "photon_sources_missing_sensor")
+        return off.astype(bool)
 
     # ---- the reference's entry point ----------------------------------------------------------
     def render(self, call: RayTracingCall, image: Optional[np.ndarray] = None) -> np.ndarray:
@@ -484,6 +504,22 @@ class Scene:
         f.argtypes = [ctypes.c_void_p]
         f.restype = ctypes.c_int
         return int(f(self.handle))
+
+    def live_sources(self):
+        """The sources a volume-free launch keeps, ascending (photon_scene_live_sources); None = every source."""
+        f = self._lib.lib.photon_scene_live_sources
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+        f.restype = ctypes.c_longlong
+        n = f(self.handle, None, 0)
+        if n == -1:
+            return None
+        if n < 0:
+            raise PhotonError(f"photon_scene_live_sources returned {n}")
+        out = np.empty(int(n), np.int32)
+        got = f(self.handle, out.ctypes.data_as(ctypes.c_void_p), int(n))
+        if got != n:
+            raise PhotonError(f"photon_scene_live_sources returned {got}, expected {n}")
+        return out
 
     def live_samples(self):
         """The lens samples a volume-free launch keeps, ascending (photon_scene_live_samples)."""

@@ -1401,6 +1401,56 @@ def test_dead_lens_samples_are_not_launched_and_nothing_changes(photon, oracle, 
         assert rel_l2(with_skip, ref) <= IMAGE_TOL, rel_l2(with_skip, ref)
 
 
+@pytest.mark.parametrize("variant", ["sample", "off_centre", "deep_sheet", "chunks", "devices"])
+def test_sources_that_miss_the_sensor_are_not_launched_and_nothing_changes(photon, oracle, monkeypatch, variant):
+    """The volume-free path also leaves out the SOURCES whose image cannot fall on the sensor (photon_scene.hip,
+    source_misses_sensor: an interval bound on where one biconvex thick lens can put a source's rays; photon's sample PIV
+    frame draws particles over a field 1.5 x wider than the camera sees, run_simulation_02.py:956-958).  The list the scene
+    launches is the complement of the host bound (tests/test_source_cull.py holds that against exact ray tracing); the image
+    with the skip equals the image without it bit for bit and equals the oracle's, which launches everything -- in one launch,
+    in several (photon_trace on sub-ranges: each launch takes its slice of the list; the 5e8-ray sample frame of
+    tests/test_sample_full_gpu.py is the multi-launch case of start_ray_tracing) and sharded over devices
+    (each shard's scene holds and culls only its own sources)."""
+    from exact_lens import lens_samples
+    call = scenes.piv_scene(n_particles=1200, rays_per_source=600, mie=True, seed=21)
+    rng = np.random.default_rng(8)
+    if variant == "off_centre":
+        call.src_x = (call.src_x + 6.0e4).astype(call.src_x.dtype)
+    if variant == "deep_sheet":
+        call.src_z = (call.src_z + rng.uniform(-1.5e5, 1.5e5, call.src_z.size)).astype(call.src_z.dtype)
+    if variant == "devices":
+        monkeypatch.setenv("PHOTON_DEVICES", "0,0,0")
+    scene = photon.scene_create(call)
+    kept = scene.live_sources()
+    scene.free()
+    off = photon.sources_missing_sensor(call, *lens_samples(photon, call))
+    assert kept is not None and np.array_equal(kept, np.flatnonzero(~off))
+    assert 0.2 * call.num_sources < kept.size < (0.8 if variant == "off_centre" else 0.6) * call.num_sources, kept.size
+    without, with_skip = _render_skip_pair(photon, call, monkeypatch)
+    assert without.sum() > 0
+    assert np.array_equal(with_skip, without), float(np.abs(with_skip - without).max())
+    ref, st = oracle.render(call)
+    assert st.rays_on_sensor > 0 and rel_l2(with_skip, ref) <= IMAGE_TOL, rel_l2(with_skip, ref)
+    if variant == "chunks":                                             # photon_trace on sub-ranges: each launch takes its slice of the list
+        import torch
+        scene = photon.scene_create(call)
+        H, W = call.image_shape
+        img = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+        total = 0
+        for b, e in ((0, 250), (250, 251), (251, 777), (777, 777), (777, call.num_sources)):
+            st = scene.trace(img.data_ptr(), None, 0, b, e, want_stats=True)
+            total += st.rays_on_sensor
+        torch.cuda.synchronize()
+        scene.free()
+        assert total == oracle.render(call)[1].rays_on_sensor
+        assert rel_l2(img.cpu().numpy().reshape(H, W), without) <= 1e-7
+    # what disables it: sensor-position noise (unbounded jitter) and the ray dumps (every ray has a slot)
+    noisy = scenes.piv_scene(n_particles=1200, rays_per_source=60, mie=False, seed=21)
+    noisy.add_pos_noise, noisy.pos_noise_std = True, 0.3
+    a, b = _render_skip_pair(photon, noisy, monkeypatch)
+    assert np.array_equal(a, b)
+
+
 def test_narrow_cones_keep_every_lens_sample(photon):
     """BOS (ray_cone_pitch_ratio 1e-4): every lens sample lands well inside the aperture; nothing is ruled out."""
     call = scenes.bos_scene(n_dots=5, points_per_dot=10, rays_per_source=64)
