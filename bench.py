@@ -381,6 +381,13 @@ def gpu_other_configs(lib, torch, workdir, with_c4, headline):
         run("PIV_sample", piv, 0, "sample-data/piv at full size: 5e4 particles x 1e4 rays = 5e8 rays, Mie, thick lens, 4-pixel splat, no volume", reps=5)
     lin = run("C3_trilinear", scenes.config("C3", workdir), 1,
               "the headline job with the trilinear sampler and the texture unit's 8-bit weights (the reference's executed path)", reps=10)
+    for name, algo in (("C3_rk45", 3), ("C3_adams_bashforth", 4)):
+        c = scenes.config("C3", workdir)
+        c.ray_tracing_algorithm = algo
+        run(name, c, 1, f"the headline job with ray_tracing_algorithm {algo} (trace_rays_through_density_gradients.h:{'304-718' if algo == 3 else '1293-1453'}, "
+                        "restated literally): in a render every ray enters through the volume's z-max face, where the reference's integrator tests "
+                        "ray_inside_box before its first step and returns the ray untouched -- the march is the move to the entry point; where "
+                        "they do march (rays from the z-min face): profiles/r06_integrators.txt", reps=10)
     eighth = scenes.bos_scene(n_dots=25, density_grad_filename=vol256)
     run("C3_eighth", eighth, 2, "one GPU's eighth of the headline job (1.25e6 rays, tricubic RK4): the strong-scaling tail at N = 8", reps=40,
         whole=headline)

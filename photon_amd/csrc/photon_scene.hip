@@ -338,11 +338,16 @@ static std::vector<int> live_lens_samples(const std::vector<float> &lx, const st
         rmax = generated->rmax;
         dmin = za < generated->zmin ? generated->zmin - za : (za > generated->zmax ? za - generated->zmax : 0.0);
     } else
-    for (size_t i = 0; i < n_sources; i++) {
-        const double x = lsp->x[i], y = lsp->y[i], r = sqrt(x * x + y * y), dd = fabs(za - (double)lsp->z[i]);
-        if (!(r == r) || !(dd == dd)) return all;                      // a NaN source: leave everything to the kernels
-        rmax = std::max(rmax, r);
-        dmin = std::min(dmin, dd);
+    {                                                                   // (one sqrt at the end: this loop runs per start_ray_tracing call)
+        double r2max = 0, nan_probe = 0;
+        for (size_t i = 0; i < n_sources; i++) {
+            const double x = lsp->x[i], y = lsp->y[i], r2 = x * x + y * y, dd = fabs(za - (double)lsp->z[i]);
+            nan_probe += r2 * 0.0 + dd * 0.0;                           // NaN (or infinity) anywhere -> NaN
+            r2max = r2 > r2max ? r2 : r2max;
+            dmin = dd < dmin ? dd : dmin;
+        }
+        if (!(nan_probe == 0.0)) return all;                           // a NaN source: leave everything to the kernels
+        rmax = sqrt(r2max);
     }
     if (!(dz == dz) || !(dmin > 16 * dz)) return all;
     std::vector<int> live;
@@ -380,20 +385,23 @@ static std::vector<int> live_lens_samples(const std::vector<float> &lx, const st
 // tests/test_parity_gpu.py::test_culled_sources_against_exact_geometry; geometries this does not cover keep every source.
 }  // extern "C"  (overloaded helpers below)
 namespace {
+#define PH_HD __host__ __device__ inline
+PH_HD double dmin2(double a, double b) { return a < b ? a : b; }
+PH_HD double dmax2(double a, double b) { return a > b ? a : b; }
 struct Ivl {
     double lo, hi;
 };
-inline Ivl iv(double a) { return Ivl{a, a}; }
-inline Ivl iv(double a, double b) { return a <= b ? Ivl{a, b} : Ivl{b, a}; }
-inline Ivl operator+(Ivl a, Ivl b) { return Ivl{a.lo + b.lo, a.hi + b.hi}; }
-inline Ivl operator-(Ivl a) { return Ivl{-a.hi, -a.lo}; }
-inline Ivl operator-(Ivl a, Ivl b) { return a + (-b); }
-inline Ivl operator*(Ivl a, Ivl b) {
+PH_HD Ivl iv(double a) { return Ivl{a, a}; }
+PH_HD Ivl iv(double a, double b) { return a <= b ? Ivl{a, b} : Ivl{b, a}; }
+PH_HD Ivl operator+(Ivl a, Ivl b) { return Ivl{a.lo + b.lo, a.hi + b.hi}; }
+PH_HD Ivl operator-(Ivl a) { return Ivl{-a.hi, -a.lo}; }
+PH_HD Ivl operator-(Ivl a, Ivl b) { return a + (-b); }
+PH_HD Ivl operator*(Ivl a, Ivl b) {
     const double c0 = a.lo * b.lo, c1 = a.lo * b.hi, c2 = a.hi * b.lo, c3 = a.hi * b.hi;
-    return Ivl{std::min(std::min(c0, c1), std::min(c2, c3)), std::max(std::max(c0, c1), std::max(c2, c3))};
+    return Ivl{dmin2(dmin2(c0, c1), dmin2(c2, c3)), dmax2(dmax2(c0, c1), dmax2(c2, c3))};
 }
-inline Ivl operator*(Ivl a, double b) { return a * iv(b); }
-inline double mag(Ivl a) { return std::max(fabs(a.lo), fabs(a.hi)); }
+PH_HD Ivl operator*(Ivl a, double b) { return a * iv(b); }
+PH_HD double mag(Ivl a) { return dmax2(fabs(a.lo), fabs(a.hi)); }
 
 struct LensCull {                       // what does not depend on the source
     bool ok = false;
@@ -450,7 +458,7 @@ static LensCull lens_cull_setup(const std::vector<float> &lx, const std::vector<
 }
 
 // true: no ray of the source (xs, ys, zs) that passes both apertures of the lens can reach a pixel
-static bool source_misses_sensor(const LensCull &c, double xs, double ys, double zs) {
+__host__ __device__ static bool source_misses_sensor(const LensCull &c, double xs, double ys, double zs) {
     const double Ds = zs - c.za;
     if (!(Ds > 0) || !(zs > c.zf + (c.zf - c.zb))) return false;
     const double rs = sqrt(xs * xs + ys * ys);
@@ -458,8 +466,8 @@ static bool source_misses_sensor(const LensCull &c, double xs, double ys, double
     const Ivl e = iv(-(c.zf - c.za) / Ds, -(c.zf - c.sag1 - c.za) / Ds);
     const double em = mag(e);
     if (!(em < 0.25)) return false;
-    const double rp = std::min(c.rp_all, (c.hp + em * rs) / (1 - em));
-    const double gmax = rs + rp, gmin = std::max(0.0, rs - rp);
+    const double rp = dmin2(c.rp_all, (c.hp + em * rs) / (1 - em));
+    const double gmax = rs + rp, gmin = dmax2(0.0, rs - rp);
     const double lmax = sqrt(gmax * gmax + Ds * Ds);
     const Ivl q = iv(1.0 / lmax, 1.0 / sqrt(gmin * gmin + Ds * Ds));
     const double su = gmax / lmax;                                      // |u_xy| at most
@@ -470,7 +478,7 @@ static bool source_misses_sensor(const LensCull &c, double xs, double ys, double
     const double s2m = sv + c.hp / c.R2a;                               // sin(incidence at the back, in the glass) at most
     if (!(c.n * s2m < 0.9)) return false;
     const Ivl a2 = iv(c.n - 1, sqrt(c.n * c.n - c.n * c.n * s2m * s2m) - sqrt(1 - c.n * c.n * s2m * s2m)) * (1.0 / c.R2a);
-    const Ivl s2 = iv(std::max(0.0, c.t - c.sag1 - c.sag2), c.t / sqrt(1 - sv * sv));
+    const Ivl s2 = iv(dmax2(0.0, c.t - c.sag1 - c.sag2), c.t / sqrt(1 - sv * sv));
     const double sw = c.n * sv + a2.hi * c.hp;                          // |w_xy| at most
     if (!(sw < 0.9)) return false;
     const Ivl tau = iv(c.zb - c.z_sen, (c.zb + c.sag2 - c.z_sen) / sqrt(1 - sw * sw));
@@ -483,6 +491,14 @@ static bool source_misses_sensor(const LensCull &c, double xs, double ys, double
     if (!(blur == blur)) return false;
     const Ivl bx = B * xs, by = B * ys;
     return bx.lo - blur > c.half_x || bx.hi + blur < -c.half_x || by.lo - blur > c.half_y || by.hi + blur < -c.half_y;
+}
+
+// One thread per source: the same bound on the device, over the scene's uploaded (or generated) source arrays -- 120 000 sources
+// cost the host 5 ms per start_ray_tracing call (more than the BOS sample image's trace), the device a few microseconds.
+__global__ __launch_bounds__(256) void source_cull_kernel(LensCull c, const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, long long n, unsigned char *__restrict__ off) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) off[i] = source_misses_sensor(c, x[i], y[i], z[i]) ? 1 : 0;
 }
 
 extern "C" {
@@ -585,6 +601,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         if ((rc = upload(s, pack, sdp->scattering_irradiance, (size_t)sdp->num_angles * sdp->num_diameters, &d.mie_irr)))
             return bail(rc);
     }
+    LensCull source_cull;
     std::vector<float> r1(lightray_number_per_particle), r2(lightray_number_per_particle);
     photon_rand_table(lightray_number_per_particle, r1.data(), r2.data());
     // x_lens = ratio * 1.0 * pitch * r1 * cos(2 pi r2), the whole product in double, then to float (.cu:123-124): the same for
@@ -609,24 +626,11 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         s->live_count = (int)live.size();
         s->live_host = live;
         if (live.size() < lx.size() && (rc = upload(s, pack, live.data(), live.size(), &s->d_live))) return bail(rc);
-        // ... and which SOURCES can reach the sensor at all (source_misses_sensor above), from the caller's arrays
+        // ... and which SOURCES can reach the sensor at all (source_misses_sensor above): decided on the device once the sources are there
         s->live_sources_known = false;
-        if (!generated && ns > 0 && lx.size() >= 2) {
-            const LensCull cull = lens_cull_setup(lx, ly, image_distance, beam_wavelength, num_elements, edp, element_center,
-                                                  element_plane_parameters, element_system_index, cam);
-            if (cull.ok) {
-                std::vector<int> keep;
-                keep.reserve(ns);
-                for (size_t i = 0; i < ns; i++)
-                    if (!source_misses_sensor(cull, lsp->x[i], lsp->y[i], lsp->z[i])) keep.push_back((int)i);
-                if (keep.size() < ns) {
-                    if (keep.empty()) keep.push_back(0);                // a launch of zero rays is nobody's friend
-                    if ((rc = upload(s, pack, keep.data(), keep.size(), &s->d_live_sources))) return bail(rc);
-                    s->live_sources = std::move(keep);
-                    s->live_sources_known = true;
-                }
-            }
-        }
+        if (ns > 0 && lx.size() >= 2)
+            source_cull = lens_cull_setup(lx, ly, image_distance, beam_wavelength, num_elements, edp, element_center,
+                                          element_plane_parameters, element_system_index, cam);
     }
     d.num_elements = num_elements;
     {
@@ -665,6 +669,36 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     reserve_zeroed(pack, kCounterBytes / sizeof(unsigned long long), &s->d_counters);
     reserve_zeroed(pack, (size_t)kQueues * kQueueStride, &s->d_queue);
     if ((rc = flush_uploads(s, pack))) return bail(rc);
+    if (source_cull.ok) {
+        // flags on the device (null stream, behind the upload), back to the host, compacted there (ascending: launches take slices
+        // of the list), the list up again: a kernel and two small copies
+        unsigned char *d_off = nullptr;
+        hipError_t he = pool_malloc((void **)&d_off, ns);
+        if (he != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
+        hipLaunchKernelGGL(source_cull_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nullptr, source_cull, d.sx, d.sy, d.sz,
+                           (long long)ns, d_off);
+        std::vector<unsigned char> off(ns);
+        he = hipGetLastError();
+        if (he == hipSuccess) he = hipMemcpy(off.data(), d_off, ns, hipMemcpyDeviceToHost);
+        pool_free(d_off);
+        if (he != hipSuccess) { fprintf(stderr, "photon: source cull failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
+        std::vector<int> keep;
+        keep.reserve(ns);
+        for (size_t i = 0; i < ns; i++)
+            if (!off[i]) keep.push_back((int)i);
+        if (keep.size() < ns) {
+            if (keep.empty()) keep.push_back(0);                        // a launch of zero rays is nobody's friend
+            int *d_keep = nullptr;
+            he = pool_malloc((void **)&d_keep, keep.size() * sizeof(int));
+            if (he != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
+            s->allocs.push_back(d_keep);
+            he = hipMemcpy(d_keep, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice);
+            if (he != hipSuccess) { fprintf(stderr, "photon: source list upload failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
+            s->d_live_sources = d_keep;
+            s->live_sources = std::move(keep);
+            s->live_sources_known = true;
+        }
+    }
     d.cam = *cam;
     d.noise = NoiseDev{0, 0, 0.f, 0.f, 0ull};
     if (cam->x_pixel_number < 1 || cam->y_pixel_number < 1) {

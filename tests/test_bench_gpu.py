@@ -52,12 +52,14 @@ def test_bench_line_contract(photon):
     assert p["launches"] == 2 and p["waves"] > 0 and p["span_ms"] > 0 and 0 <= p["drain_ms"] < p["span_ms"]
     o = d["gpu_other_configs"]                           # the other BASELINE configs, GPU legs
     # one GPU's share of every 8-GPU configuration next to the whole job on this GPU
-    assert set(o) == {"C2", "PIV_sample", "C3_trilinear", "C3_eighth", "C3_trilinear_eighth", "C5", "C5_eighth", "C4", "C4_eighth"}
+    assert set(o) == {"C2", "PIV_sample", "C3_rk45", "C3_adams_bashforth", "C3_trilinear", "C3_eighth", "C3_trilinear_eighth", "C5", "C5_eighth", "C4", "C4_eighth"}
     assert o["C2"]["rays"] == 1000000 and o["C2"]["kernel_ms"] is None and o["C2"]["rays_on_sensor"] > 0
     assert o["C2"]["atomics_per_s"] > 1e9 and o["C2"]["sensor_taps"] > 3 * o["C2"]["rays_on_sensor"]         # four taps per ray that lands
     assert o["PIV_sample"]["rays"] == 500_000_000 and 0 < o["PIV_sample"]["rays_launched"] < 0.35 * o["PIV_sample"]["rays"]
     assert o["C2"]["rays_launched"] < 0.6 * o["C2"]["rays"] and 20 < o["C2"]["launched"]["sources"] < 100    # half the field is outside the camera's view
-    for k in set(o) - {"C2", "PIV_sample"}:
+    for k in ("C3_rk45", "C3_adams_bashforth"):                                # in a render: the move to the entry point only (no iterations)
+        assert o[k]["ms"] > 0 and o[k]["kernel_ms"] > 0 and o[k]["rays_marched"] == o[k]["rays"] == o[k]["rays_on_sensor"], k
+    for k in set(o) - {"C2", "PIV_sample", "C3_rk45", "C3_adams_bashforth"}:
         assert o[k]["ms"] > 0 and o[k]["kernel_ms"] > 0 and o[k]["clock_mhz"] > 500 and o[k]["rays_marched"] > 0 and o[k]["fixed_ms"] > 0, k
     assert (o["C4"]["rays"], o["C4_eighth"]["rays"], o["C5"]["rays"], o["C5_eighth"]["rays"]) == (100_000_000, 12_500_000, 40_000_000, 5_000_000)
     assert o["C5_eighth"]["rays_marched"] < o["C5_eighth"]["rays"]             # doomed rays were skipped
