@@ -287,6 +287,28 @@ __device__ __forceinline__ float front_axis_distance(const element_data_t &e, f3
     return nanf("");
 }
 
+// Stage 1a for one launch slot (parallel_ray_tracing.cu:2004-2082): generate the ray and move it into the volume's world frame;
+// a ray aimed so far outside the first element's aperture that no deflection the volume can produce brings it back
+// (SceneDev::doom_margin, launch_chunk) is marked dead (NaN position): the march skips it, the sensor stage drops it as it
+// would after the lens.  ONE body for raygen_kernel and for the march kernels' own prologue (march_kernel.hpp): same bits.
+struct RayPD { f3 p, d; };
+__device__ __forceinline__ RayPD generate_state(const SceneDev &sc, long long src_begin, unsigned n_rays, unsigned r, double &radiance) {
+    int source, local_ray;
+    slot_to_ray(sc, src_begin, n_rays, r, source, local_ray);
+    const Ray ray = generate_ray(sc, source, local_ray);
+    f3 p = ray.pos, d = ray.dir;
+    p.z = (float)(p.z - (sc.z_offset + 750e3));                         // .cu:2045
+    p = matvec(sc.cam.inverse_rotation_matrix, p);                      // camera -> world
+    d = matvec(sc.cam.inverse_rotation_matrix, d);
+    if (sc.doom_margin > 0.f) {
+        const float dist = front_axis_distance(sc.elems[0], mk3(sc.centers[0][0], sc.centers[0][1], sc.centers[0][2]),
+                                               sc.planes[0], ray);
+        if (dist > sc.elems[0].element_geometry.pitch / 2.0 + sc.doom_margin) p = nan3();
+    }
+    radiance = ray.radiance;
+    return RayPD{p, d};
+}
+
 // The WORKING element train (train_mode 1; the reference advertises it, its device code is a stub; the
 // sequential branch of its numpy ancestor, perform_ray_tracing_03.py:1419-1485, runs and pins this one
 // through tests/golden/train_f64.npz, the simultaneous-elements branch :1254-1417 does not): groups in

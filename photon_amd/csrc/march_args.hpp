@@ -128,6 +128,13 @@ struct MarchArgs {
     unsigned epoch;                     // tag of this launch in RayStateDev::seg_flag
     unsigned *error;                    // waves that gave a segment up (zero unless the hand-off between segments is broken)
     unsigned chunk_shift;               // log2 of the groups per queue chunk (launch_march)
+    // Ray generation folded into the march (round 6): gen != 0 = no raygen_kernel ran; the wave that takes the FIRST piece of a
+    // group generates its rays itself (generate_state: the kernel's own body) from this copy of the scene description, read
+    // through the argument segment where it is used, and writes only what the sensor stage needs beside the marched state:
+    // the radiance, and the NaN position of a ray that is not marched.
+    unsigned gen;
+    long long src_begin;
+    SceneDev scene;
 };
 typedef const __attribute__((address_space(4))) MarchArgs *MarchArgsPtr;
 

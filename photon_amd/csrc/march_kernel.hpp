@@ -67,6 +67,17 @@ constexpr int kSegPollMax = 1 << 20;                            // polls (~2 us 
 constexpr unsigned kSegDone = 0xffu;                            // seg_flag: every ray of the group has left the volume
 constexpr unsigned kSegPoison = 0xfeu;                          // seg_flag: a wave gave a segment of this group up (counted in MarchArgs::error)
 
+// Ray generation inside the march (MarchArgs::gen): out of line, so that the march loop's register allocation sees a call
+// with six values coming back and nothing of the f64 generation code or the scene description.  The scene is read through
+// a generic pointer into the argument segment (global loads, cached; once per ray).
+__device__ __attribute__((noinline)) RayPD raygen_in_march(const SceneDev *sc, long long src_begin, unsigned n_rays, unsigned r,
+                                                           double *radiance_out) {
+    double radiance;
+    const RayPD g = generate_state(*sc, src_begin, n_rays, r, radiance);
+    radiance_out[r] = radiance;
+    return g;
+}
+
 // One item of the launch: segment `seg` of 64-ray group `group` -- load the state, march, store it back.  Must be called
 // by all 64 lanes of the wave.  With MarchArgs::segments == 1 (seg = 0) this is the whole march of the group.
 //
@@ -130,7 +141,13 @@ __device__ __forceinline__ void march_group(unsigned group, unsigned seg, unsign
             // workgroups per CU, uneven arrivals) by tools/ubench/xcd_handoff.hip: 0 stale words of 7.4e7 with or without it.
             // An acquire per segment start invalidates the L1 under the CU's nineteen other waves' texel blocks.
         }
-        if (has_ray) {
+        const bool gen = fresh && a->gen != 0u;                 // wave-uniform: this wave generates the group's rays itself
+        if (has_ray && gen) {
+            const RayPD g = raygen_in_march((const SceneDev *)&a->scene, a->src_begin, n_rays, r, st.radiance);
+            p = g.p; d = g.d;
+            marching = !isnan3(p);
+            if (!marching) { st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z; st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z; }     // what the sensor stage reads of a ray that is not marched
+        } else if (has_ray) {
             // segmented launches: sc1 loads (the words may have been stored by a wave on another XCD a moment ago); whole
             // marches read what raygen_kernel wrote before this kernel started: plain loads
             p = SEG ? mk3(ld_agent(&st.px[r]), ld_agent(&st.py[r]), ld_agent(&st.pz[r])) : mk3(st.px[r], st.py[r], st.pz[r]);

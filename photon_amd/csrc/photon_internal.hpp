@@ -181,8 +181,9 @@ int ensure_workspace(photon_scene *s, size_t rays);
 
 // ---- photon_march.hip ----
 // The march launch of n rays whose state sits in the scene's workspace (stage 1b): persistent grid, work queues, segments.
+// gen_src_begin >= 0: no raygen_kernel has run; the march generates the rays of sources [gen_src_begin, ...) itself (algorithms 1, 2)
 int launch_march(photon_scene *s, const photon_volume *vol, int algorithm, unsigned n, unsigned long long ray_base,
-                 const InterDump &idump, bool save, hipStream_t stream, hipEvent_t ev_march_begin);
+                 const InterDump &idump, bool save, hipStream_t stream, hipEvent_t ev_march_begin, long long gen_src_begin = -1);
 // Did any march wave give a segment up?  Reads (and clears) the scene's error word; the caller has synchronised.
 int march_error_check(photon_scene *scene);
 int profile_reset(photon_scene *s, hipStream_t stream);

@@ -197,7 +197,7 @@ namespace photon {
 
 // The march launch of n rays whose state sits in the scene's workspace (stage 1b): persistent grid, work queues, segments.
 int launch_march(photon_scene *s, const photon_volume *vol, int algorithm, unsigned n, unsigned long long ray_base,
-                        const InterDump &idump, bool save, hipStream_t stream, hipEvent_t ev_march_begin) {
+                        const InterDump &idump, bool save, hipStream_t stream, hipEvent_t ev_march_begin, long long gen_src_begin) {
     const dim3 block(256), grid((n + 255) / 256);
     const int interp = vol->dev.interpolation;
     const f4 *tex = interp == 2 ? vol->d_coeffs : vol->d_texels;
@@ -228,6 +228,7 @@ int launch_march(photon_scene *s, const photon_volume *vol, int algorithm, unsig
     margs.vol = vol->dev; margs.tex = tex; margs.n_rays = n; margs.st = s->ws; margs.counters = s->d_counters; margs.noise = s->dev.noise;
     margs.ray_base = ray_base; margs.idump = idump; margs.queue = s->d_queue; margs.profile = profile; margs.segments = segments;
     margs.epoch = s->march_epoch; margs.error = scene_error_word(s);
+    if (gen_src_begin >= 0 && (algorithm == 1 || algorithm == 2)) { margs.gen = 1u; margs.src_begin = gen_src_begin; margs.scene = s->dev; }
     // queue chunks: small ones (tail balance) for the tricubic kernels where neighbouring groups are neighbouring SOURCES and
     // the volume is small enough for every L2 to hold what its waves touch; lens-major launches (neighbouring groups share
     // a lens tile, their rays fan out over the whole volume) and large volumes keep the L2-friendly 128 -- C5 at a

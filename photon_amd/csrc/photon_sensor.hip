@@ -12,24 +12,12 @@ using namespace photon;
 __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st) {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
-    int source, local_ray;
-    slot_to_ray(sc, src_begin, n_rays, r, source, local_ray);
-    const Ray ray = generate_ray(sc, source, local_ray);
-    f3 p = ray.pos, d = ray.dir;
-    p.z = (float)(p.z - (sc.z_offset + 750e3));                         // .cu:2045
-    p = matvec(sc.cam.inverse_rotation_matrix, p);                      // camera -> world
-    d = matvec(sc.cam.inverse_rotation_matrix, d);
-    if (sc.doom_margin > 0.f) {
-        // aimed so far outside the first element's aperture that no deflection the volume can produce brings it
-        // back (margin from the volume's largest gradient, launch_chunk): dead on arrival -- mark it, the march
-        // skips it, the sensor stage drops it as it would after the lens.  Half of a full-aperture PIV cone.
-        const float dist = front_axis_distance(sc.elems[0], mk3(sc.centers[0][0], sc.centers[0][1], sc.centers[0][2]),
-                                               sc.planes[0], ray);
-        if (dist > sc.elems[0].element_geometry.pitch / 2.0 + sc.doom_margin) p = nan3();
-    }
+    double radiance;
+    const RayPD g = generate_state(sc, src_begin, n_rays, r, radiance);
+    const f3 p = g.p, d = g.d;
     st.px[r] = p.x; st.py[r] = p.y; st.pz[r] = p.z;
     st.dx[r] = d.x; st.dy[r] = d.y; st.dz[r] = d.z;
-    st.radiance[r] = ray.radiance;
+    st.radiance[r] = radiance;
 }
 
 // Stage 2: everything after the volume (parallel_ray_tracing.cu:2136-2241): back to the camera frame, lens / aperture /

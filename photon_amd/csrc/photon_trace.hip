@@ -127,6 +127,12 @@ static bool launches_live_sources_only(const photon_scene *s, const photon_volum
            first_aperture_applies(s);
 }
 
+// PHOTON_RAYGEN=kernel|fold (read once): where the rays of a launch through a volume are generated
+static bool raygen_folded() {
+    static const bool fold = [] { const char *e = getenv("PHOTON_RAYGEN"); return !(e && strcmp(e, "kernel") == 0); }();
+    return fold;
+}
+
 int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long long src_begin,
                         long long src_end, DumpDev dump, hipStream_t stream, hipEvent_t ev_march_begin, hipEvent_t ev_march_end) {
     const bool live_only = launches_live_samples_only(s, vol, dump);
@@ -163,13 +169,17 @@ int launch_chunk(photon_scene *s, const photon_volume *vol, int algorithm, long 
         int rc = ensure_workspace(s, n);
         if (rc) return rc;
         s->launched = true;                                     // from here on kernels of this scene may be in flight (scene_quiesce)
-        rc = launch_raygen(s, src_begin, n, stream);
-        if (rc) return rc;
+        // ray generation: a kernel of its own (PHOTON_RAYGEN=kernel), or the prologue of the march's first piece (fold)
+        const bool fold = raygen_folded() && (algorithm == 1 || algorithm == 2);
+        if (!fold) {
+            rc = launch_raygen(s, src_begin, n, stream);
+            if (rc) return rc;
+        }
         const int interp = vol->dev.interpolation;
         const unsigned long long ray_base = (unsigned long long)(s->dev.source_base + src_begin) * (unsigned)s->dev.rays_per_source;
         const InterDump idump{dump.inter_pos, dump.inter_dir, dump.inter_slots, dump.num_save, 0u};
         const bool save = dump.inter_pos != nullptr && interp == 1;     // only the trilinear branches record
-        rc = launch_march(s, vol, algorithm, n, ray_base, idump, save, stream, ev_march_begin);
+        rc = launch_march(s, vol, algorithm, n, ray_base, idump, save, stream, ev_march_begin, fold ? src_begin : -1);
         if (rc) return rc;
         if (ev_march_end) PH_CHECK(hipEventRecord(ev_march_end, stream));
         return launch_sensor(s, true, src_begin, n, dump, stream);

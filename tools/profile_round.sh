@@ -2,7 +2,8 @@
 # rocprofv3 evidence for profiles/<tag>_*: per workload one kernel-trace pass and four PMC passes (each counter set in its
 # own run, no tracing alongside).      tools/profile_round.sh <tag> [workload ...]
 #   workloads: cubic (C3 headline), linear (C3, the reference's sampler), euler_cubic, euler_linear, c5 (incoherent launch,
-#              1/4 size), tail (one GPU's eighth of C3: bench.py --dots 25), c4 (the whole 1e8-ray 512^3 job, kernel stats only)
+#              1/4 size), tail (one GPU's eighth of C3: bench.py --dots 25), c4 (the whole 1e8-ray 512^3 job, kernel stats only),
+#              piv (the reference's sample PIV frame at full size through start_ray_tracing)
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 tag=${1:-r03}; shift || true
@@ -24,6 +25,7 @@ for w in "${wl[@]}"; do
     tail) cmd="$BT --steps 100"; pcmd="$BT --steps 20" ;;
     c4) cmd="$B --volume 512 --dots 2000"; pmc=0 ;;
     c5) cmd="$ROOT/tools/c5_full.py 0.25" ;;
+    piv) cmd="$ROOT/tools/sample_full.py piv_full" ;;          # the reference's sample PIV frame (5e8 requested rays, no volume): sensor_kernel<false,false>
     *) echo "unknown workload $w"; exit 1 ;;
   esac
   d="$out/$w"; mkdir -p "$d"

@@ -13,7 +13,8 @@ from conftest import load_fixture_call  # noqa: E402
 from photon_amd.library import PhotonLibrary  # noqa: E402
 
 lib = PhotonLibrary()
-for case in ("piv_full", "bos_full_im1", "bos_full_im2"):
+cases = sys.argv[1:] or ["piv_full", "bos_full_im1", "bos_full_im2"]        # python tools/sample_full.py [case ...]
+for case in cases:
     call = load_fixture_call(case)
     lib.render(call)
     best = 1e9
