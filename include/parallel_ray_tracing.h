@@ -134,7 +134,11 @@ typedef struct camera_design_t {
  *   PHOTON_NOISE_SEED=u64        seed of the add_pos_noise / add_ngrad_noise generators (the
  *                                reference seeds cuRAND with time(NULL); default 0x5eed)
  *   PHOTON_ELEMENT_TRAIN=reference|sequential   element-group walk (photon_scene_set_element_train)
- *   PHOTON_SKIP_DOOMED=0|1       1 (default): rays that provably die on the first aperture are not marched
+ *   PHOTON_SKIP_DOOMED=0|1       1 (default): rays that provably die on the first aperture are not marched; without a volume
+ *                                the lens samples no source can get through it and the sources whose image cannot fall on the
+ *                                sensor are not launched (photon_scene_set_skip_doomed); the image is the same bit for bit
+ *   PHOTON_RAYGEN=fold|kernel    where the rays of a launch through a volume are generated: in the prologue of the march's
+ *                                first piece (default) or by a kernel of its own; same bits (read once per process)
  *   PHOTON_RAY_ORDER=source|lens|auto           lane order of a launch (photon_scene_set_ray_order)
  *   PHOTON_DEVICES=all|0,1,..    shard the sources of one call over several GPUs: one host thread per
  *                                device uploads only its block of the sources, the NRRD is parsed once, the
