@@ -341,7 +341,7 @@ int photon_scene_live_rays(const photon_scene_t *scene);
 /* the kept lens samples themselves, ascending (out: room for `capacity` >= photon_scene_live_rays entries); returns their number, -1 on a bad argument */
 int photon_scene_live_samples(const photon_scene_t *scene, int *out, int capacity);
 /* The same switch also leaves out, on the volume-free path, the SOURCES whose image cannot fall on the sensor (one biconvex
- * thick lens on the axis, host source arrays, no sensor-position noise, no dumps: photon_scene.hip, source_misses_sensor --
+ * thick lens or one thin lens on the axis, no sensor-position noise, no dumps: photon_scene.hip, source_misses_sensor --
  * an interval bound on where the lens can put the source's rays; photon's sample PIV frame draws particles over a field 1.5 x
  * wider than the camera sees, run_simulation_02.py:956-958).  The image is unchanged.  photon_scene_live_sources: the sources
  * that are launched, ascending (out may be NULL to ask for the count); -1 when nothing could be ruled out (all are), -2 on a

@@ -364,7 +364,7 @@ static std::vector<int> live_lens_samples(const std::vector<float> &lx, const st
 // volume-free path.  photon's sample PIV frame draws its particles over a field 1.5 x wider than the camera sees
 // (run_simulation_02.py:956-958): more than half of them image beside the sensor.
 //
-// One biconvex thick lens ('l', on the z axis, normal +z), then the sensor plane z = z_sensor.  Everything a surviving ray
+// One biconvex thick lens ('l', on the z axis, normal +z) -- or one thin lens ('t': lens_cull_setup) --, then the sensor plane z = z_sensor.  Everything a surviving ray
 // does is, in the xy plane, a linear combination of two vectors -- its aim point P on the plane z = image_distance (.cu:123-141)
 // and its source's S = (x_s, y_s) -- with SCALAR coefficients, because the lens is rotationally symmetric and every surface
 // normal's xy part is the hit point's over the radius:
@@ -405,6 +405,8 @@ PH_HD double mag(Ivl a) { return dmax2(fabs(a.lo), fabs(a.hi)); }
 
 struct LensCull {                       // what does not depend on the source
     bool ok = false;
+    bool thin = false;                  // element 't': one refraction on the element's plane (.cu:416-503); focal = its focal length
+    double focal = 0;
     double za, zf, zb, z_sen, R1, R2a, n, hp, t, sag1, sag2, rp_all, half_x, half_y;
 };
 }  // namespace
@@ -413,7 +415,7 @@ static LensCull lens_cull_setup(const std::vector<float> &lx, const std::vector<
                                 int num_elements, const element_data_t *edp, const double (*center)[3], const double (*plane)[4],
                                 const int *sys_index, const camera_design_t *cam) {
     LensCull c;
-    if (num_elements < 1 || edp[0].element_type != 'l') return c;
+    if (num_elements < 1 || (edp[0].element_type != 'l' && edp[0].element_type != 't')) return c;
     // the reference's element path sends the ray through element 0 once per single-member group (.cu:1331-1333): exactly once here
     {
         const int n = std::min(num_elements, kMaxElements);
@@ -428,6 +430,29 @@ static LensCull lens_cull_setup(const std::vector<float> &lx, const std::vector<
     }
     if (plane[0][0] != 0.0 || plane[0][1] != 0.0 || !(plane[0][2] > 0.0) || center[0][0] != 0.0 || center[0][1] != 0.0) return c;
     const element_data_t &e = edp[0];
+    if (e.element_type == 't') {
+        // Thin lens: the ray meets the element's plane at H, within pitch / 2 of the axis, and leaves along u - (H - C) / f
+        // (.cu:447-503).  With the centre ON the plane the z component of that is u's, so the sensor hit is
+        //     h = H (1 - s / f) + s u_xy,   s = (z_plane - z_sensor) / |u_z|,   H = (1 + e) P - e S,  e = (z_plane - z_a) / (z_a - z_s):
+        // exact up to the one quantity that depends on P, |P - S| in s / f (source_misses_sensor: an interval again).
+        c.thin = true;
+        c.focal = (double)(float)e.element_properties.thin_lens_focal_length;
+        c.hp = (double)(float)e.element_geometry.pitch / 2.0;
+        const double z_plane = -plane[0][3] / plane[0][2];
+        if (!(c.focal > 0) || !(c.hp > 0) || !(fabs(z_plane - center[0][2]) <= 1e-9 * fabs(z_plane) + 1e-9)) return c;
+        c.za = image_distance;
+        c.zf = c.zb = z_plane;
+        c.z_sen = cam->z_sensor;
+        c.t = c.sag1 = c.sag2 = 0; c.R1 = c.R2a = 0; c.n = 1;
+        if (!(c.zb > c.z_sen) || !(cam->pixel_pitch > 0)) return c;
+        double rp = 0;
+        for (size_t k = 0; k < lx.size(); k++) rp = std::max(rp, sqrt((double)lx[k] * lx[k] + (double)ly[k] * ly[k]));
+        c.rp_all = rp * (1 + 1e-6);
+        c.half_x = (double)cam->pixel_pitch * (cam->x_pixel_number + 1) / 2.0 + cam->pixel_pitch;
+        c.half_y = (double)cam->pixel_pitch * (cam->y_pixel_number + 1) / 2.0 + cam->pixel_pitch;
+        c.ok = c.za == c.za && c.zf == c.zf && c.half_x == c.half_x && c.half_y == c.half_y;
+        return c;
+    }
     c.R1 = e.element_geometry.front_surface_radius;
     c.R2a = -(double)e.element_geometry.back_surface_radius;
     c.hp = (double)(float)e.element_geometry.pitch / 2.0;                // the kernels compare against the f32 pitch
@@ -463,6 +488,23 @@ __host__ __device__ static bool source_misses_sensor(const LensCull &c, double x
     if (!(Ds > 0) || !(zs > c.zf + (c.zf - c.zb))) return false;
     const double rs = sqrt(xs * xs + ys * ys);
     if (!(rs == rs)) return false;
+    if (c.thin) {
+        if (!(zs > c.zf + 1e-3 * Ds)) return false;
+        const double e = -(c.zf - c.za) / Ds;                           // exact: the hit lies ON the plane
+        if (!(fabs(e) < 0.25)) return false;
+        const double rp = dmin2(c.rp_all, (c.hp + fabs(e) * rs) / (1 - fabs(e)));
+        const double gmax = rs + rp, gmin = dmax2(0.0, rs - rp);
+        // s / f = (z_plane - z_sensor) |P - S| / ((z_s - z_a) f): the flight to the sensor in units of the focal length
+        const double k0 = (c.zf - c.z_sen) / (Ds * c.focal);
+        const Ivl sig = iv(k0 * sqrt(gmin * gmin + Ds * Ds), k0 * sqrt(gmax * gmax + Ds * Ds));
+        const double m1 = (c.zf - c.z_sen) / Ds;                        // s u_xy = m1 (P - S), exactly
+        const Ivl one_sig = iv(1.0) - sig;
+        const Ivl A = one_sig * (1 + e) + iv(m1), B = one_sig * (-e) - iv(m1);
+        const double blur = mag(A) * rp + 1e-5 * (Ds + (c.zf - c.z_sen)) + 10.0;
+        if (!(blur == blur)) return false;
+        const Ivl bx = B * xs, by = B * ys;
+        return bx.lo - blur > c.half_x || bx.hi + blur < -c.half_x || by.lo - blur > c.half_y || by.hi + blur < -c.half_y;
+    }
     const Ivl e = iv(-(c.zf - c.za) / Ds, -(c.zf - c.sag1 - c.za) / Ds);
     const double em = mag(e);
     if (!(em < 0.25)) return false;

@@ -68,3 +68,22 @@ def call_lens(call):
     g = e["element_geometry"]
     return (float(call.element_center[0][2]), float(g["vertex_distance"]), float(g["front_surface_radius"]),
             float(g["back_surface_radius"]), float(e["element_properties"]["refractive_index"]), float(g["pitch"]))
+
+
+def trace_thin_lens(sources, px, py, z_aim, z_plane, focal, pitch, z_sensor, margin=0.0):
+    """The 't' element (.cu:416-503): the ray meets the plane z = z_plane (the element's centre lies on it, on the axis) at H,
+    dies beyond pitch / 2 + margin from the axis, leaves along u - (H - C) / f.  Returns (hits [ns, np, 2], alive [ns, np])."""
+    S = np.asarray(sources, np.float64)
+    ns, npnt = S.shape[0], len(px)
+    d = np.stack([px[None, :] - S[:, 0:1], py[None, :] - S[:, 1:2], np.broadcast_to(z_aim - S[:, 2:3], (ns, npnt))], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t = (z_plane - S[:, None, 2]) / d[..., 2]
+        H = S[:, None, :] + d * t[..., None]
+        alive = np.hypot(H[..., 0], H[..., 1]) <= pitch / 2 + margin
+        w = d - (H - np.array([0.0, 0.0, z_plane])) / focal
+        w /= np.linalg.norm(w, axis=-1, keepdims=True)
+        tt = (z_sensor - H[..., 2]) / w[..., 2]
+        hits = H[..., :2] + w[..., :2] * tt[..., None]
+    alive &= np.isfinite(hits).all(-1)
+    return hits, alive

@@ -1401,10 +1401,10 @@ def test_dead_lens_samples_are_not_launched_and_nothing_changes(photon, oracle, 
         assert rel_l2(with_skip, ref) <= IMAGE_TOL, rel_l2(with_skip, ref)
 
 
-@pytest.mark.parametrize("variant", ["sample", "off_centre", "deep_sheet", "chunks", "devices"])
+@pytest.mark.parametrize("variant", ["sample", "off_centre", "deep_sheet", "chunks", "devices", "thin_lens"])
 def test_sources_that_miss_the_sensor_are_not_launched_and_nothing_changes(photon, oracle, monkeypatch, variant):
     """The volume-free path also leaves out the SOURCES whose image cannot fall on the sensor (photon_scene.hip,
-    source_misses_sensor: an interval bound on where one biconvex thick lens can put a source's rays; photon's sample PIV
+    source_misses_sensor: an interval bound on where one biconvex thick lens -- or one thin lens -- can put a source's rays; photon's sample PIV
     frame draws particles over a field 1.5 x wider than the camera sees, run_simulation_02.py:956-958).  The list the scene
     launches is the complement of the host bound (tests/test_source_cull.py holds that against exact ray tracing); the image
     with the skip equals the image without it bit for bit and equals the oracle's, which launches everything -- in one launch,
@@ -1420,6 +1420,8 @@ def test_sources_that_miss_the_sensor_are_not_launched_and_nothing_changes(photo
         call.src_z = (call.src_z + rng.uniform(-1.5e5, 1.5e5, call.src_z.size)).astype(call.src_z.dtype)
     if variant == "devices":
         monkeypatch.setenv("PHOTON_DEVICES", "0,0,0")
+    if variant == "thin_lens":
+        call.elements[0]["element_type"] = "t"                          # photon's thin-lens model: the bound is the exact linear map
     scene = photon.scene_create(call)
     kept = scene.live_sources()
     scene.free()

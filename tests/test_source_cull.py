@@ -1,13 +1,13 @@
 """The bound behind the source cull of the volume-free path (photon_scene.hip, source_misses_sensor) on its own: host
 arithmetic of the product library, no GPU -- held against exact float64 ray tracing of EVERY ray of EVERY source it rules
-out, over hundreds of random thick-lens cameras (focal length, f-number, both radii, thickness, index, object distance,
+out, over hundreds of random thick-lens (and, one in five, thin-lens) cameras (focal length, f-number, both radii, thickness, index, object distance,
 field, cone) including ones the sample data never visits."""
 import copy
 
 import numpy as np
 import pytest
 
-from exact_lens import call_lens, lens_samples, trace_thick_lens
+from exact_lens import call_lens, lens_samples, trace_thick_lens, trace_thin_lens
 from photon_amd import scenes
 from photon_amd.library import PhotonLibrary
 
@@ -32,8 +32,13 @@ def _check(lib, call, px, py, min_margin=1.0):
     hx, hy = _sensor_half(call)
     # every ray of every culled source, apertures opened by a micron: none may come within a micron of a pixel
     if off.any():
-        hits, alive = trace_thick_lens(S[off], px, py, float(call.image_distance), zc, t, R1, R2, n, pitch,
-                                       float(call.camera["z_sensor"]), margin=1.0)
+        if call.elements[0]["element_type"] == "t":
+            hits, alive = trace_thin_lens(S[off], px, py, float(call.image_distance), zc,
+                                          float(call.elements[0]["element_properties"]["thin_lens_focal_length"]), pitch,
+                                          float(call.camera["z_sensor"]), margin=1.0)
+        else:
+            hits, alive = trace_thick_lens(S[off], px, py, float(call.image_distance), zc, t, R1, R2, n, pitch,
+                                           float(call.camera["z_sensor"]), margin=1.0)
         near = alive & (np.abs(hits[..., 0]) <= hx + min_margin) & (np.abs(hits[..., 1]) <= hy + min_margin)
         assert not near.any(), (int(near.sum()), call_lens(call))
     return off, S
@@ -79,6 +84,9 @@ def test_random_cameras(lib, seed):
             g["back_surface_radius"] *= rng.uniform(0.7, 1.6)
             g["vertex_distance"] += rng.uniform(0, 0.05 * f)
             e["element_properties"]["refractive_index"] = float(rng.uniform(1.3, 2.0))
+        if trial % 5 == 4:                                              # every fifth camera carries photon's thin lens instead
+            e["element_type"] = "t"
+            e["element_properties"]["thin_lens_focal_length"] = float(f * rng.uniform(0.8, 1.3))
         call.elements = [e]
         call.lens_pitch, call.image_distance = geom["lens_pitch"], geom["image_distance"]
         call.element_center, call.element_plane_parameters = geom["element_center"], geom["element_plane_parameters"]
@@ -108,7 +116,9 @@ def test_geometries_the_bound_does_not_cover_keep_everything(lib):
         edit(c)
         return lib.sources_missing_sensor(c, px, py)
 
-    def thin(c): c.elements[0]["element_type"] = "t"
+    def thin_off_plane(c):                                              # a thin lens whose centre is not on its plane
+        c.elements[0]["element_type"] = "t"
+        c.element_center = np.array([[0.0, 0.0, c.element_center[0][2] + 5.0]])
     def tilted(c): c.element_plane_parameters = np.array([[0.02, 0.0, 1.0, c.element_plane_parameters[0][3]]])
     def flipped(c): c.element_plane_parameters = -np.asarray(c.element_plane_parameters)
     def off_axis(c): c.element_center = np.array([[50.0, 0.0, c.element_center[0][2]]])
@@ -119,8 +129,12 @@ def test_geometries_the_bound_does_not_cover_keep_everything(lib):
         c.element_center = np.repeat(np.asarray(c.element_center), 2, 0)
         c.element_plane_parameters = np.repeat(np.asarray(c.element_plane_parameters), 2, 0)
         c.element_system_index = np.array([2, 1], np.int32)
-    for edit in (thin, tilted, flipped, off_axis, concave, twice):
+    for edit in (thin_off_plane, tilted, flipped, off_axis, concave, twice):
         assert variant(edit) is None, edit.__name__
+    c = copy.deepcopy(base)                                              # photon's thin lens in place of the thick one: covered
+    c.elements[0]["element_type"] = "t"
+    off_thin = lib.sources_missing_sensor(c, px, py)
+    assert off_thin is not None and 0.3 < off_thin.mean() < 0.7
     # sources at or below the lens are kept one by one
     c = copy.deepcopy(base)
     c.src_z = np.asarray(c.src_z).copy()
