@@ -662,6 +662,22 @@ def test_scene_generation_on_device(photon, oracle, monkeypatch, tmp_path):
     o_img, _ = oracle.render(pcall)
     assert rel_l2(host_img, o_img) <= IMAGE_TOL
     scene.free(); s.free()
+    # a field wider than the camera sees (photon's sample frame: 1.5 x): the sources that miss the sensor are ruled out on the
+    # device from the GENERATED arrays exactly as the host bound rules them out from their download
+    from exact_lens import lens_samples
+    wide = photon.sources_piv(78, 2000, (-7.5e4, -7.5e4, -7.5e3), (7.5e4, 7.5e4, 7.5e3), z_obj, 730.0, 500.0, cdf)
+    d = wide.download()
+    wcall = scenes.piv_scene(n_particles=2000, rays_per_source=200, mie=True, polydisperse=True, seed=3)
+    wcall.src_x, wcall.src_y, wcall.src_z = d["x"], d["y"], d["z"]
+    wcall.src_radiance, wcall.src_diameter_index = d["radiance"], d["diameter_index"]
+    scene = photon.scene_create_from_sources(wcall, wide)
+    kept = scene.live_sources()
+    off = photon.sources_missing_sensor(wcall, *lens_samples(photon, wcall))
+    assert kept is not None and np.array_equal(kept, np.flatnonzero(~off)) and 0.3 * 2000 < kept.size < 0.6 * 2000
+    img = torch.zeros(host_img.size, dtype=torch.float32, device="cuda")
+    scene.trace(img.data_ptr())
+    assert np.array_equal(img.cpu().numpy().reshape(host_img.shape), photon.render(wcall))
+    scene.free(); wide.free()
 
 
 @pytest.mark.parametrize("interp", [1, 2])
