@@ -606,6 +606,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         return 1;
     }
     photon_scene *s = new photon_scene();
+    (void)hipGetDevice(&s->device);                             // first: the failure paths below free into this device's block cache
     SceneDev &d = s->dev;
     UploadPack pack;
     int rc = 0;
@@ -751,10 +752,8 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     if (e != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(e)); return bail((int)e); }
     {
         int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            s->device = dev;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) s->num_cus = cus;
-        }
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            s->num_cus = cus;
     }
     for (auto &ev : s->ev) {
         e = hipEventCreate(&ev);
