@@ -501,6 +501,12 @@ const char *photon_version(void);
  * within [2^-96, 2^96] in magnitude (a marching ray's sit within a few binades of 1); tests hold them against numpy. */
 int photon_selftest_normal_range_math(int n, const float *a, const float *b, float *quot, float *rcp, float *root);
 
+/* Self-test hook: perm_out[k] = index (in [first, first + n)) of the k-th of the sources first .. first + n - 1 of the host
+ * arrays x, y (n_total entries) in the spatial order lens-major launches use -- Morton order on a 2^16 x 2^16 grid over the
+ * range's bounding box, one scale for both axes, ties in the caller's order -- computed by the device path (bounding box,
+ * keys, the library's own stable radix sort: photon_amd/csrc/photon_sort.hip); tests hold it against numpy's stable argsort. */
+int photon_selftest_morton_order(const float *x, const float *y, long long n_total, long long first, long long n, int *perm_out);
+
 /* Device-to-device float4 streaming copy of `bytes` bytes, `reps` times: read + write rate in GB/s -- the HBM rate a
  * trivial kernel reaches on this GPU, which bench.py prints next to the 8 TB/s specification. */
 int photon_measure_copy_gbs(size_t bytes, int reps, double *gbs_out);

@@ -28,7 +28,7 @@ DECLARED_SYMBOLS = (
     "photon_sources_bos", "photon_sources_piv", "photon_sources_count", "photon_sources_download", "photon_sources_free",
     "photon_scene_create_from_sources", "photon_volume_gaussian", "photon_density_gaussian_write_nrrd",
     # section 4: sensor post-processing on the device
-    "photon_postprocess_u16", "photon_measure_copy_gbs", "photon_selftest_normal_range_math",
+    "photon_postprocess_u16", "photon_measure_copy_gbs", "photon_selftest_normal_range_math", "photon_selftest_morton_order",
 )
 
 
@@ -203,6 +203,17 @@ class PhotonLibrary:
         r2 = np.empty(n, np.float32)
         self._check(self.lib.photon_rand_table(n, _ptr(r1), _ptr(r2)), "photon_rand_table")
         return r1, r2
+
+    def morton_order(self, x, y, first: int = 0, n: Optional[int] = None):
+        """photon_selftest_morton_order: the spatial order of sources first .. first + n - 1, as the device computes it."""
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        n = x.size - first if n is None else int(n)
+        out = np.empty(n, np.int32)
+        f = self.lib.photon_selftest_morton_order
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p]
+        self._check(f(_ptr(x), _ptr(y), int(x.size), int(first), n, _ptr(out)), "photon_selftest_morton_order")
+        return out
 
     def sources_missing_sensor(self, call: RayTracingCall, lens_x, lens_y):
         """photon_sources_missing_sensor (host arithmetic, no GPU needed): bool[num_sources], True = no ray of that source

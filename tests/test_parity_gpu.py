@@ -1469,6 +1469,42 @@ def test_sources_that_miss_the_sensor_are_not_launched_and_nothing_changes(photo
     assert np.array_equal(a, b)
 
 
+def _morton_keys_numpy(x, y):
+    """photon_sort.hip's keys in numpy: one scale for both axes over the range's bounding box, f64 arithmetic, truncation."""
+    x, y = x.astype(np.float64), y.astype(np.float64)
+    ext = max(x.max() - x.min(), y.max() - y.min())
+    f = 65535.0 / ext if ext > 0 else 0.0
+    ix, iy = ((x - x.min()) * f).astype(np.uint64) & 0xffff, ((y - y.min()) * f).astype(np.uint64) & 0xffff
+
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+    return (spread(ix) | (spread(iy) << 1)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("n,first,count", [(1, 0, 1), (63, 0, 63), (4096, 0, 4096), (4097, 0, 4097), (100_003, 0, 100_003),
+                                           (100_003, 777, 50_000), (1_000_000, 0, 1_000_000), (300_000, 0, 300_000)])
+def test_morton_order_is_numpys_stable_argsort(photon, n, first, count):
+    """The hand-written stable radix sort behind lens-major launches (photon_sort.hip: four passes of eight bits; histogram,
+    scan, a scatter in which one wave ranks its tile with ballots) against numpy: the permutation is EXACTLY the stable
+    argsort of the Morton keys -- ties (sources in one grid cell; here a fifth of the points are duplicates of others) keep the
+    caller's order -- for sizes around the tile and wave boundaries, a sub-range, and C5's million."""
+    rng = np.random.default_rng(n + first)
+    x = rng.uniform(-3.0e4, 3.0e4, n).astype(np.float32)
+    y = rng.uniform(-7.5e3, 9.0e3, n).astype(np.float32)               # a strip: one scale for both axes
+    if n > 10:
+        dup = rng.integers(0, n, n // 5)
+        x[dup], y[dup] = x[(dup * 7 + 1) % n], y[(dup * 7 + 1) % n]     # exact ties
+    if n == 300_000:
+        x[:], y[:] = np.float32(12.5), np.float32(-3.0)                 # every key equal: the identity
+    got = photon.morton_order(x, y, first, count)
+    keys = _morton_keys_numpy(x[first:first + count], y[first:first + count])
+    want = first + np.argsort(keys, kind="stable").astype(np.int32)
+    assert np.array_equal(got, want), int(np.flatnonzero(got != want)[0])
+
+
 def test_narrow_cones_keep_every_lens_sample(photon):
     """BOS (ray_cone_pitch_ratio 1e-4): every lens sample lands well inside the aperture; nothing is ruled out."""
     call = scenes.bos_scene(n_dots=5, points_per_dot=10, rays_per_source=64)
