@@ -491,6 +491,12 @@ constexpr unsigned kSplatStride = 2 * kSplatSlots * sizeof(double);      // byte
 struct SplatLds {                           // one wave's area: 8 KiB (five 256-thread blocks per CU)
     float4 head[64];                        // 4-pixel splat: bits(ii), bits(jj), inc0, inc1 (the erf splat reads its rays' windows from registers)
     double f[64][2 * kSplatSlots];          // erf: scale * d_erf(column c0 + j), j < 7 | d_erf(row r0 + j)   4-pixel: [0] = inc2, inc3
+    __device__ __forceinline__ float2 &tail(int r) { return *reinterpret_cast<float2 *>(&f[r][0]); }
+};
+struct TapLds {                             // the 4-pixel splat on its own (a camera without diffraction: sensor_kernel's SPLAT = 2): 1.5 KiB per wave
+    float4 head[64];
+    float2 more[64];                        // inc2, inc3
+    __device__ __forceinline__ float2 &tail(int r) { return more[r]; }
 };
 
 // largest f32 t with sqrtf(t) <= r: the radius test sqrtf(s) <= r is then s <= t, exactly (sqrtf is correctly rounded
@@ -781,7 +787,8 @@ __device__ __forceinline__ int bilinear_splat_lane(double *image, int W, int H, 
 // Wave-cooperative form (see erf_splat_wave): rays park (ii_ul, jj_ul, four increments), lanes become the pixels of
 // 8x8 tiles of the wave's window and sum what the parked rays add to them; one atomic per pixel per wave.  Must be
 // called by all 64 lanes.
-__device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, const TapReq &q, SplatLds &lds) {
+template <class LDS>
+__device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, const TapReq &q, LDS &lds) {
     const unsigned long long any = ballot(q.valid);
     if (any == 0) return 0;
     const int lane = threadIdx.x & 63;
@@ -792,7 +799,7 @@ __device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, 
     if (tiles_x * tiles_y > kSplatTiles) return q.valid ? bilinear_splat_lane(image, W, H, q) : 0;  // wave-uniform
     if (q.valid) {
         lds.head[lane] = make_float4(__int_as_float(q.ii_ul), __int_as_float(q.jj_ul), q.inc[0], q.inc[1]);
-        *reinterpret_cast<float2 *>(&lds.f[lane][0]) = make_float2(q.inc[2], q.inc[3]);
+        lds.tail(lane) = make_float2(q.inc[2], q.inc[3]);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -810,7 +817,7 @@ __device__ __forceinline__ int bilinear_splat_wave(double *image, int W, int H, 
                 const int r = __ffsll((long long)rays) - 1;
                 rays &= rays - 1;
                 const float4 h = lds.head[r];
-                const float2 h2 = *reinterpret_cast<const float2 *>(&lds.f[r][0]);
+                const float2 h2 = lds.tail(r);
                 const int di = ii - __float_as_int(h.x), dj = jj - __float_as_int(h.y);
                 if (lands && (unsigned)di <= 1u && (unsigned)dj <= 1u) {
                     const float inc = di ? (dj ? h2.y : h2.x) : (dj ? h.w : h.z);

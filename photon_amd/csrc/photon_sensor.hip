@@ -29,10 +29,19 @@ __global__ __launch_bounds__(256) void raygen_kernel(SceneDev sc, long long src_
 #ifndef PHOTON_SENSOR_WAVES
 #define PHOTON_SENSOR_WAVES 5           // the cooperative splats park 8 KiB per wave in LDS: five blocks per CU
 #endif
-template <bool FROM_STATE, bool TRAIN>
-__global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
+// SPLAT: 0 = which splat a ray gets is decided where it lands (apparent image / diffraction spot / 4 pixels: the camera's
+// switches); 2 = a camera WITHOUT diffraction behind a real first element -- every ray takes the 4-pixel splat (photon's PIV
+// frames): the instantiation carries neither the erf code nor its 8 KiB of parked factors per wave, so more waves fit
+// (PHOTON_SENSOR_WAVES_TAPS) under the f64 generation chains it waits on.
+#ifndef PHOTON_SENSOR_WAVES_TAPS
+#define PHOTON_SENSOR_WAVES_TAPS 6
+#endif
+template <int SPLAT> struct SplatArea { typedef SplatLds type; };
+template <> struct SplatArea<2> { typedef TapLds type; };
+template <bool FROM_STATE, bool TRAIN, int SPLAT>
+__global__ __launch_bounds__(256, (SPLAT == 2 ? PHOTON_SENSOR_WAVES_TAPS : PHOTON_SENSOR_WAVES)) void sensor_kernel(SceneDev sc, long long src_begin, unsigned n_rays, RayStateDev st,
                                                      double *image, DumpDev dump, unsigned long long *counters) {
-    __shared__ SplatLds splat_lds[4];                                   // per wave: the parked rays of the cooperative splats
+    __shared__ typename SplatArea<SPLAT>::type splat_lds[4];            // per wave: the parked rays of the cooperative splats
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     int taps = 0;
     unsigned on_sensor = 0;
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
                 dump.final_dir[3 * r] = ray.dir.x; dump.final_dir[3 * r + 1] = ray.dir.y;
                 dump.final_dir[3 * r + 2] = ray.dir.z;
             }
-            if (sc.elems[0].element_type == 'n') {                      // .cu:2143-2158
+            if (SPLAT != 2 && sc.elems[0].element_type == 'n') {        // .cu:2143-2158
                 const float z_obj = sc.object_distance + sc.z_offset;
                 fin = apparent_image(ray, sc.cam, z_obj, sc.z_offset, sc.elems[0], req, sc.noise, ray_id);
                 have_fin = true;
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
             } else {
                 ray = optical_system<TRAIN>(sc, ray);
                 if (!(isnan3(ray.dir) || isnan3(ray.pos))) {            // .cu:2172-2176
-                    if (sc.cam.implement_diffraction) {
+                    if (SPLAT != 2 && sc.cam.implement_diffraction) {
                         fin = sensor_diffraction(ray, sc.cam, req, sc.noise, ray_id);
                         have_fin = true;
                         on_sensor = !isnan(fin.x);
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256, PHOTON_SENSOR_WAVES) void sensor_kernel(SceneD
             dump.final_pos[3 * r] = fin.x; dump.final_pos[3 * r + 1] = fin.y; dump.final_pos[3 * r + 2] = fin.z;
         }
     }
-    taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req, splat_lds[threadIdx.x >> 6]);      // all 64 lanes
+    if constexpr (SPLAT != 2) taps += erf_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, req, splat_lds[threadIdx.x >> 6]);      // all 64 lanes
     taps += bilinear_splat_wave(image, sc.cam.x_pixel_number, sc.cam.y_pixel_number, tap, splat_lds[threadIdx.x >> 6]);     // all 64 lanes
     wave_add(&counter_slot(counters)[CNT_TAPS], (unsigned long long)taps);
     wave_add(&counter_slot(counters)[CNT_ON_SENSOR], (unsigned long long)on_sensor);
@@ -123,12 +132,15 @@ int launch_raygen(photon_scene *s, long long src_begin, unsigned n, hipStream_t 
 int launch_sensor(photon_scene *s, bool from_state, long long src_begin, unsigned n, const DumpDev &dump, hipStream_t stream) {
     const dim3 block(256), grid((n + 255) / 256);
     double *d_image = s->d_acc;
-    if (from_state) {
-        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<true, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
-        else hipLaunchKernelGGL((sensor_kernel<true, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+    // a camera without diffraction behind a real first element: the 4-pixel-only instantiation (the default element path, without a march)
+    const bool taps_only = !from_state && !s->dev.train_mode && !s->dev.cam.implement_diffraction && s->dev.elems[0].element_type != 'n';
+    if (taps_only) hipLaunchKernelGGL((sensor_kernel<false, false, 2>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+    else if (from_state) {
+        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<true, true, 0>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        else hipLaunchKernelGGL((sensor_kernel<true, false, 0>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     } else {
-        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<false, true>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
-        else hipLaunchKernelGGL((sensor_kernel<false, false>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<false, true, 0>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+        else hipLaunchKernelGGL((sensor_kernel<false, false, 0>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     }
     PH_CHECK(hipGetLastError());
     return 0;
