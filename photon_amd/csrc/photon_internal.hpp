@@ -92,6 +92,16 @@ struct photon_sources {                 // light-field sources generated in HBM 
 
 struct PermEntry { long long begin = -1, end = -1; int *d_perm = nullptr; size_t capacity = 0; unsigned long long stamp = 0; };
 
+namespace photon {
+// What the source cull of the volume-free path needs beside a source's coordinates (photon_scene.hip, source_misses_sensor)
+struct LensCull {
+    bool ok = false;
+    bool thin = false;                  // element 't': one refraction on the element's plane (.cu:416-503); focal = its focal length
+    double focal = 0;
+    double za, zf, zb, z_sen, R1, R2a, n, hp, t, sag1, sag2, rp_all, half_x, half_y;
+};
+}  // namespace photon
+
 struct photon_scene {
     photon::SceneDev dev{};
     std::vector<void *> allocs;         // device buffers owned by the scene
@@ -131,6 +141,8 @@ struct photon_scene {
     const int *d_live_sources = nullptr;    // the sources whose image can fall on the sensor (photon_scene.hip, source_misses_sensor), ascending;
     std::vector<int> live_sources;      // part of the upload block, and the same list on the host; used by the volume-free path only
     bool live_sources_known = false;    // false: nothing could be ruled out (or the geometry is not covered): every source is launched
+    bool live_sources_tried = false;    // the device pass has run (ensure_live_sources: with the scene's first volume-free launch)
+    photon::LensCull source_cull;       // set at creation (host arithmetic only)
     PermEntry perms[4];                 // spatial (Morton) orders of the lens-major launch ranges seen last
     unsigned long long perm_clock = 0;
     photon_sort_scratch sort_scratch;   // keys / indices / radix-sort temporaries, grown on demand (photon_sort.hip)
@@ -176,6 +188,7 @@ int cached_volume(const char *path, int interpolation, photon_volume **out, Shar
 // Wait for the device before blocks of this scene go back to the cache (its kernels may still be using them); no-op for a
 // scene that never launched anything.
 void scene_quiesce(photon_scene *s);
+int ensure_live_sources(photon_scene *s);
 void free_resume_state(photon_scene *s);
 int ensure_workspace(photon_scene *s, size_t rays);
 

@@ -403,18 +403,12 @@ PH_HD Ivl operator*(Ivl a, Ivl b) {
 PH_HD Ivl operator*(Ivl a, double b) { return a * iv(b); }
 PH_HD double mag(Ivl a) { return dmax2(fabs(a.lo), fabs(a.hi)); }
 
-struct LensCull {                       // what does not depend on the source
-    bool ok = false;
-    bool thin = false;                  // element 't': one refraction on the element's plane (.cu:416-503); focal = its focal length
-    double focal = 0;
-    double za, zf, zb, z_sen, R1, R2a, n, hp, t, sag1, sag2, rp_all, half_x, half_y;
-};
 }  // namespace
 
-static LensCull lens_cull_setup(const std::vector<float> &lx, const std::vector<float> &ly, float image_distance, float beam_wavelength,
+static photon::LensCull lens_cull_setup(const std::vector<float> &lx, const std::vector<float> &ly, float image_distance, float beam_wavelength,
                                 int num_elements, const element_data_t *edp, const double (*center)[3], const double (*plane)[4],
                                 const int *sys_index, const camera_design_t *cam) {
-    LensCull c;
+    photon::LensCull c;
     if (num_elements < 1 || (edp[0].element_type != 'l' && edp[0].element_type != 't')) return c;
     // the reference's element path sends the ray through element 0 once per single-member group (.cu:1331-1333): exactly once here
     {
@@ -483,7 +477,7 @@ static LensCull lens_cull_setup(const std::vector<float> &lx, const std::vector<
 }
 
 // true: no ray of the source (xs, ys, zs) that passes both apertures of the lens can reach a pixel
-__host__ __device__ static bool source_misses_sensor(const LensCull &c, double xs, double ys, double zs) {
+__host__ __device__ static bool source_misses_sensor(const photon::LensCull &c, double xs, double ys, double zs) {
     const double Ds = zs - c.za;
     if (!(Ds > 0) || !(zs > c.zf + (c.zf - c.zb))) return false;
     const double rs = sqrt(xs * xs + ys * ys);
@@ -537,7 +531,7 @@ __host__ __device__ static bool source_misses_sensor(const LensCull &c, double x
 
 // One thread per source: the same bound on the device, over the scene's uploaded (or generated) source arrays -- 120 000 sources
 // cost the host 5 ms per start_ray_tracing call (more than the BOS sample image's trace), the device a few microseconds.
-__global__ __launch_bounds__(256) void source_cull_kernel(LensCull c, const float *__restrict__ x, const float *__restrict__ y,
+__global__ __launch_bounds__(256) void source_cull_kernel(photon::LensCull c, const float *__restrict__ x, const float *__restrict__ y,
                                                           const float *__restrict__ z, long long n, unsigned char *__restrict__ off) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) off[i] = source_misses_sensor(c, x[i], y[i], z[i]) ? 1 : 0;
@@ -644,7 +638,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
         if ((rc = upload(s, pack, sdp->scattering_irradiance, (size_t)sdp->num_angles * sdp->num_diameters, &d.mie_irr)))
             return bail(rc);
     }
-    LensCull source_cull;
+    photon::LensCull source_cull;
     std::vector<float> r1(lightray_number_per_particle), r2(lightray_number_per_particle);
     photon_rand_table(lightray_number_per_particle, r1.data(), r2.data());
     // x_lens = ratio * 1.0 * pitch * r1 * cos(2 pi r2), the whole product in double, then to float (.cu:123-124): the same for
@@ -712,36 +706,7 @@ static int scene_create_impl(float lens_pitch, float image_distance, const scatt
     reserve_zeroed(pack, kCounterBytes / sizeof(unsigned long long), &s->d_counters);
     reserve_zeroed(pack, (size_t)kQueues * kQueueStride, &s->d_queue);
     if ((rc = flush_uploads(s, pack))) return bail(rc);
-    if (source_cull.ok) {
-        // flags on the device (null stream, behind the upload), back to the host, compacted there (ascending: launches take slices
-        // of the list), the list up again: a kernel and two small copies
-        unsigned char *d_off = nullptr;
-        hipError_t he = pool_malloc((void **)&d_off, ns);
-        if (he != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
-        hipLaunchKernelGGL(source_cull_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nullptr, source_cull, d.sx, d.sy, d.sz,
-                           (long long)ns, d_off);
-        std::vector<unsigned char> off(ns);
-        he = hipGetLastError();
-        if (he == hipSuccess) he = hipMemcpy(off.data(), d_off, ns, hipMemcpyDeviceToHost);
-        pool_free(d_off);
-        if (he != hipSuccess) { fprintf(stderr, "photon: source cull failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
-        std::vector<int> keep;
-        keep.reserve(ns);
-        for (size_t i = 0; i < ns; i++)
-            if (!off[i]) keep.push_back((int)i);
-        if (keep.size() < ns) {
-            if (keep.empty()) keep.push_back(0);                        // a launch of zero rays is nobody's friend
-            int *d_keep = nullptr;
-            he = pool_malloc((void **)&d_keep, keep.size() * sizeof(int));
-            if (he != hipSuccess) { fprintf(stderr, "photon: hipMalloc failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
-            s->allocs.push_back(d_keep);
-            he = hipMemcpy(d_keep, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice);
-            if (he != hipSuccess) { fprintf(stderr, "photon: source list upload failed: %s\n", hipGetErrorString(he)); return bail((int)he); }
-            s->d_live_sources = d_keep;
-            s->live_sources = std::move(keep);
-            s->live_sources_known = true;
-        }
-    }
+    s->source_cull = source_cull;                               // the device pass runs with the first volume-free launch (ensure_live_sources)
     d.cam = *cam;
     d.noise = NoiseDev{0, 0, 0.f, 0.f, 0ull};
     if (cam->x_pixel_number < 1 || cam->y_pixel_number < 1) {
@@ -807,8 +772,8 @@ int photon_sources_missing_sensor(const float *lens_x, const float *lens_y, int 
         n < 0 || (n > 0 && (!x || !y || !z || !off))) return 2;
     for (long long i = 0; i < n; i++) off[i] = 0;
     const std::vector<float> lx(lens_x, lens_x + n_samples), ly(lens_y, lens_y + n_samples);
-    const LensCull cull = lens_cull_setup(lx, ly, image_distance, beam_wavelength, num_elements, edp, element_center,
-                                          element_plane_parameters, element_system_index, cam);
+    const photon::LensCull cull = lens_cull_setup(lx, ly, image_distance, beam_wavelength, num_elements, edp, element_center,
+                                                  element_plane_parameters, element_system_index, cam);
     if (!cull.ok) return 1;
     for (long long i = 0; i < n; i++) off[i] = source_misses_sensor(cull, x[i], y[i], z[i]) ? 1 : 0;
     return 0;
@@ -817,6 +782,7 @@ int photon_sources_missing_sensor(const float *lens_x, const float *lens_y, int 
 // The sources the volume-free path launches (ascending indices), or -1 when every source is (nothing could be ruled out)
 long long photon_scene_live_sources(const photon_scene_t *s, int *out, long long capacity) {
     if (!s) return -2;
+    if (photon::ensure_live_sources(const_cast<photon_scene_t *>(s))) return -2;
     if (!s->live_sources_known) return -1;
     const long long n = (long long)s->live_sources.size();
     if (out) {
@@ -835,6 +801,42 @@ int photon_scene_set_skip_doomed(photon_scene_t *s, int on) {
 }  // extern "C"
 
 namespace photon {
+
+// The sources whose image can fall on the sensor (source_misses_sensor), decided ONCE per scene, with its first volume-free
+// launch (a scene that only ever marches through a volume -- C3, C5, every shard of a PHOTON_DEVICES call -- never pays the
+// kernel and the two small copies): flags on the device (null stream; the sources were uploaded when the scene was created),
+// back to the host, compacted there (ascending: launches take slices of the list), the list up again.
+int ensure_live_sources(photon_scene *s) {
+    if (s->live_sources_tried) return 0;
+    s->live_sources_tried = true;
+    s->live_sources_known = false;
+    const size_t ns = (size_t)s->dev.num_sources;
+    if (!s->source_cull.ok || ns == 0) return 0;
+    DeviceScope on_scene_device(s->device);
+    unsigned char *d_off = nullptr;
+    PH_CHECK(pool_malloc((void **)&d_off, ns));
+    hipLaunchKernelGGL(source_cull_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nullptr, s->source_cull, s->dev.sx, s->dev.sy, s->dev.sz,
+                       (long long)ns, d_off);
+    std::vector<unsigned char> off(ns);
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpy(off.data(), d_off, ns, hipMemcpyDeviceToHost);
+    pool_free(d_off);
+    PH_CHECK(he);
+    std::vector<int> keep;
+    keep.reserve(ns);
+    for (size_t i = 0; i < ns; i++)
+        if (!off[i]) keep.push_back((int)i);
+    if (keep.size() == ns) return 0;
+    if (keep.empty()) keep.push_back(0);                                // a launch of zero rays is nobody's friend
+    int *d_keep = nullptr;
+    PH_CHECK(pool_malloc((void **)&d_keep, keep.size() * sizeof(int)));
+    s->allocs.push_back(d_keep);
+    PH_CHECK(hipMemcpy(d_keep, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice));
+    s->d_live_sources = d_keep;
+    s->live_sources = std::move(keep);
+    s->live_sources_known = true;
+    return 0;
+}
 
 void scene_quiesce(photon_scene *s) {
     if (!s->launched) return;

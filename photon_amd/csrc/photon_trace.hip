@@ -122,9 +122,10 @@ static bool launches_live_samples_only(const photon_scene *s, const photon_volum
 }
 // ... and only the sources whose image can fall on the sensor (photon_scene.hip, source_misses_sensor): same conditions, no
 // sensor-position noise (unbounded), the scene's source list as it was created
-static bool launches_live_sources_only(const photon_scene *s, const photon_volume *vol, const DumpDev &dump) {
-    return !vol && s->skip_doomed && s->live_sources_known && !dump.final_pos && !dump.inter_pos && !s->dev.noise.add_pos &&
-           first_aperture_applies(s);
+static bool launches_live_sources_only(photon_scene *s, const photon_volume *vol, const DumpDev &dump) {
+    if (vol || !s->skip_doomed || dump.final_pos || dump.inter_pos || s->dev.noise.add_pos || !first_aperture_applies(s)) return false;
+    if (ensure_live_sources(s)) return false;               // the scene's first volume-free launch decides the list (a failure: everything is launched)
+    return s->live_sources_known;
 }
 
 // PHOTON_RAYGEN=kernel|fold (read once): where the rays of a launch through a volume are generated

