@@ -1,4 +1,6 @@
-"""bench.py end to end on the GPU at a small size: the JSON contract the driver parses, the roofline object, the live
+"""(The file name sorts after every parity file: bench.py runs child profiler passes and a dozen configurations -- under
+`pytest -x` a failure here must not keep the oracle comparisons from running.)
+bench.py end to end on the GPU at a small size: the JSON contract the driver parses, the roofline object, the live
 HBM-traffic measurement (child rocprofv3 --pmc passes) and the CPU-baseline leg."""
 import json
 import os
