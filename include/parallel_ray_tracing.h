@@ -343,7 +343,9 @@ int photon_scene_live_samples(const photon_scene_t *scene, int *out, int capacit
 /* The same switch also leaves out, on the volume-free path, the SOURCES whose image cannot fall on the sensor (one biconvex
  * thick lens or one thin lens on the axis, no sensor-position noise, no dumps: photon_scene.hip, source_misses_sensor --
  * an interval bound on where the lens can put the source's rays; photon's sample PIV frame draws particles over a field 1.5 x
- * wider than the camera sees, run_simulation_02.py:956-958).  The image is unchanged.  photon_scene_live_sources: the sources
+ * wider than the camera sees, run_simulation_02.py:956-958).  The image is unchanged.  The list is made once per scene, by its
+ * first volume-free photon_trace (or by the query below): one small kernel and two small copies on the null stream, for which
+ * that call waits -- a scene that only marches through a volume never pays them.  photon_scene_live_sources: the sources
  * that are launched, ascending (out may be NULL to ask for the count); -1 when nothing could be ruled out (all are), -2 on a
  * bad argument. */
 long long photon_scene_live_sources(const photon_scene_t *scene, int *out, long long capacity);
