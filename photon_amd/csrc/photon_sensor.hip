@@ -132,9 +132,10 @@ int launch_raygen(photon_scene *s, long long src_begin, unsigned n, hipStream_t 
 int launch_sensor(photon_scene *s, bool from_state, long long src_begin, unsigned n, const DumpDev &dump, hipStream_t stream) {
     const dim3 block(256), grid((n + 255) / 256);
     double *d_image = s->d_acc;
-    // a camera without diffraction behind a real first element: the 4-pixel-only instantiation (the default element path, without a march)
-    const bool taps_only = !from_state && !s->dev.train_mode && !s->dev.cam.implement_diffraction && s->dev.elems[0].element_type != 'n';
-    if (taps_only) hipLaunchKernelGGL((sensor_kernel<false, false, 2>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+    // a camera without diffraction behind a real first element: the 4-pixel-only instantiations (the default element path; after a march: C5)
+    const bool taps_only = !s->dev.train_mode && !s->dev.cam.implement_diffraction && s->dev.elems[0].element_type != 'n';
+    if (taps_only && !from_state) hipLaunchKernelGGL((sensor_kernel<false, false, 2>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
+    else if (taps_only) hipLaunchKernelGGL((sensor_kernel<true, false, 2>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
     else if (from_state) {
         if (s->dev.train_mode) hipLaunchKernelGGL((sensor_kernel<true, true, 0>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
         else hipLaunchKernelGGL((sensor_kernel<true, false, 0>), grid, block, 0, stream, s->dev, src_begin, n, s->ws, d_image, dump, s->d_counters);
