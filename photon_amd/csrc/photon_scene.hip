@@ -467,6 +467,9 @@ static photon::LensCull lens_cull_setup(const std::vector<float> &lx, const std:
     c.sag1 = c.R1 - sqrt(c.R1 * c.R1 - c.hp * c.hp);
     c.sag2 = c.R2a - sqrt(c.R2a * c.R2a - c.hp * c.hp);
     if (!(c.zb > c.z_sen) || !(cam->pixel_pitch > 0)) return c;
+    // the two caps must not meet inside the aperture (the glass path of a surviving ray is then >= 0, which the bound on H2 uses);
+    // photon's own lens has t = sag1 + sag2 exactly (run_simulation_02.py: zero edge thickness), hence the tolerance
+    if (!(c.t >= 0.999 * (c.sag1 + c.sag2))) return c;
     double rp = 0;
     for (size_t k = 0; k < lx.size(); k++) rp = std::max(rp, sqrt((double)lx[k] * lx[k] + (double)ly[k] * ly[k]));
     c.rp_all = rp * (1 + 1e-6);

@@ -123,13 +123,14 @@ def test_geometries_the_bound_does_not_cover_keep_everything(lib):
     def flipped(c): c.element_plane_parameters = -np.asarray(c.element_plane_parameters)
     def off_axis(c): c.element_center = np.array([[50.0, 0.0, c.element_center[0][2]]])
     def concave(c): c.elements[0]["element_geometry"]["back_surface_radius"] = 2.0e5
+    def caps_meet(c): c.elements[0]["element_geometry"]["vertex_distance"] *= 0.5       # thinner than its two sags: the caps cross inside the aperture
 
     def twice(c):                                                       # element 0 applied twice by the reference's element path
         c.elements = [c.elements[0], copy.deepcopy(c.elements[0])]
         c.element_center = np.repeat(np.asarray(c.element_center), 2, 0)
         c.element_plane_parameters = np.repeat(np.asarray(c.element_plane_parameters), 2, 0)
         c.element_system_index = np.array([2, 1], np.int32)
-    for edit in (thin_off_plane, tilted, flipped, off_axis, concave, twice):
+    for edit in (thin_off_plane, tilted, flipped, off_axis, concave, caps_meet, twice):
         assert variant(edit) is None, edit.__name__
     c = copy.deepcopy(base)                                              # photon's thin lens in place of the thick one: covered
     c.elements[0]["element_type"] = "t"
