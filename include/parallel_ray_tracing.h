@@ -121,7 +121,7 @@ typedef struct camera_design_t {
  *   ray_tracing_algorithm  1 euler, 2 rk4, 3 rk45, 4 adams-bashforth; any other value leaves the ray
  *                      straight (the reference's `default: break`, trace_rays_...h:1537).  3 and 4
  *                      are restated literally, trilinear on the raw volume whatever PHOTON_INTERP
- *   density_grad_filename  NRRD (type float, dim 3, raw little-endian), "" when unused
+ *   density_grad_filename  NRRD (type float, dimension 3; encoding raw, gzip or ascii; either byte order), "" when unused
  *   save_lightrays     writes <pos_path>/pos_%04d.bin, <dir_path>/dir_%04d.bin per chunk
  * All pointers are borrowed for the duration of the call.  No error channel (void):
  * on failure a message goes to stderr and image_array is left unmodified.

@@ -65,7 +65,7 @@ def rocm_lib_dir() -> str:
 def link_flags():
     lib = rocm_lib_dir()
     return ["-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-Wl,--enable-new-dtags", f"-Wl,-rpath,{lib}", f"-L{lib}",
-            "-lamdhip64"]
+            "-lamdhip64", "-lz"]        # zlib: gzip-encoded NRRD payloads (photon_volume.hip, parse_nrrd)
 
 
 def needs_build() -> bool:

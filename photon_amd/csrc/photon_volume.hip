@@ -1,6 +1,7 @@
 // photon_volume.hip - the refractive-index-gradient volume: NRRD parser, the kernels that build the float4 texels
 // (grad n, n-1) and their cubic B-spline coefficients, the volume handle API and the per-device volume cache of
 // start_ray_tracing.  HBM-bound one-off work (0.15 + 0.7 ms at 256^3), cached across calls.
+#include <zlib.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -185,7 +186,12 @@ static bool parse_nrrd(const char *path, std::vector<float> &rho, int dims[3], d
     }
     if (dimension != 3 || !sizes_ok) { why = "need dimension 3 with three sizes"; return false; }
     if (type != "float") { why = "type must be float (single precision)"; return false; }
-    if (encoding != "raw" || endian != "little") { why = "only raw little-endian encoding is supported"; return false; }
+    // payload encodings teem's nrrdLoad (what the reference reads its volume with, .h:1687) takes and people's tools write: raw
+    // (photon's own writer, nrrd_functions.py:49), gzip (pynrrd's default), ascii; either byte order
+    const bool is_raw = encoding == "raw", is_gzip = encoding == "gzip" || encoding == "gz",
+               is_ascii = encoding == "ascii" || encoding == "text" || encoding == "txt";
+    if (!is_raw && !is_gzip && !is_ascii) { why = "encoding must be raw, gzip or ascii"; return false; }
+    if (endian != "little" && endian != "big") { why = "endian must be little or big"; return false; }
     if (dims[0] < 3 || dims[1] < 3 || dims[2] < 3) { why = "each axis needs at least 3 samples"; return false; }
     // a corrupt header must not drive the allocation: the payload has to be in the file
     if (dims[0] > 65536 || dims[1] > 65536 || dims[2] > 65536) { why = "sizes beyond 65536 per axis"; return false; }
@@ -194,10 +200,51 @@ static bool parse_nrrd(const char *path, std::vector<float> &rho, int dims[3], d
     f.seekg(0, std::ios::end);
     const std::streamoff total = f.tellg();
     f.seekg(here, std::ios::beg);
-    if (here < 0 || total < here || (unsigned long long)(total - here) < count * sizeof(float)) { why = "payload shorter than sizes"; return false; }
-    rho.resize((size_t)count);
-    f.read(reinterpret_cast<char *>(rho.data()), (std::streamsize)(rho.size() * sizeof(float)));
-    if ((size_t)f.gcount() != rho.size() * sizeof(float)) { why = "payload shorter than sizes"; return false; }
+    if (here < 0 || total < here) { why = "payload shorter than sizes"; return false; }
+    const unsigned long long in_file = (unsigned long long)(total - here);
+    if (is_raw) {
+        if (in_file < count * sizeof(float)) { why = "payload shorter than sizes"; return false; }
+        rho.resize((size_t)count);
+        f.read(reinterpret_cast<char *>(rho.data()), (std::streamsize)(rho.size() * sizeof(float)));
+        if ((size_t)f.gcount() != rho.size() * sizeof(float)) { why = "payload shorter than sizes"; return false; }
+    } else if (is_ascii) {
+        // at least two characters per value (a digit and a separator) have to be there before anything is allocated
+        if (in_file < 2 * count - 1) { why = "payload shorter than sizes"; return false; }
+        rho.resize((size_t)count);
+        for (size_t i = 0; i < rho.size(); i++)
+            if (!(f >> rho[i])) { why = "payload shorter than sizes"; return false; }
+    } else {
+        // gzip: the compressed bytes are in the file; deflate's best ratio is ~1032 : 1, so sizes a file cannot hold are refused
+        // before the allocation, and the stream is never inflated beyond what the sizes ask for
+        if (in_file < 18 || count * sizeof(float) / 1032ull > in_file) { why = "payload shorter than sizes"; return false; }
+        std::vector<unsigned char> z((size_t)in_file);
+        f.read(reinterpret_cast<char *>(z.data()), (std::streamsize)z.size());
+        if ((size_t)f.gcount() != z.size()) { why = "cannot read the compressed payload"; return false; }
+        rho.resize((size_t)count);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 32) != Z_OK) { why = "zlib initialisation failed"; return false; }     // zlib or gzip wrapper
+        const unsigned long long want = count * sizeof(float);
+        unsigned long long got = 0, fed = 0;
+        int zr = Z_OK;
+        while (zr == Z_OK && got < want) {                              // in pieces of < 4 GiB: zlib counts in 32 bits
+            if (zs.avail_in == 0) {
+                const unsigned long long piece = std::min<unsigned long long>(z.size() - fed, 1ull << 30);
+                if (piece == 0) break;
+                zs.next_in = z.data() + fed; zs.avail_in = (uInt)piece; fed += piece;
+            }
+            const unsigned long long room = std::min<unsigned long long>(want - got, 1ull << 30);
+            zs.next_out = reinterpret_cast<unsigned char *>(rho.data()) + got; zs.avail_out = (uInt)room;
+            zr = inflate(&zs, Z_NO_FLUSH);
+            got += room - zs.avail_out;
+        }
+        inflateEnd(&zs);
+        if ((zr != Z_OK && zr != Z_STREAM_END) || got != want) { why = "compressed payload is damaged or shorter than sizes"; return false; }
+    }
+    if (endian == "big" && !is_ascii) {
+        unsigned *u = reinterpret_cast<unsigned *>(rho.data());
+        for (size_t i = 0; i < rho.size(); i++) u[i] = __builtin_bswap32(u[i]);
+    }
     return true;
 }
 

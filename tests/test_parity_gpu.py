@@ -1315,6 +1315,55 @@ def test_nrrd_header_cannot_drive_the_allocation(photon, tmp_path):
         assert L.photon_volume_load_nrrd(str(p).encode(), 1, ctypes.byref(h)) != 0 and not h.value
 
 
+def test_nrrd_payload_encodings(photon, oracle, tmp_path):
+    """The volume file as other tools write it: teem's nrrdLoad -- what the reference reads it with (.h:1687) -- takes gzip
+    (pynrrd's default), ascii and either byte order beside photon's own raw little-endian.  Every encoding of one density
+    field loads to the SAME texels, bit for bit, as the raw file (and as the oracle's build of the array); damaged or
+    dishonest compressed payloads are refused with an error code, nothing allocated on their say-so."""
+    import ctypes
+    import gzip
+    import zlib
+    rng = np.random.default_rng(3)
+    n = (12, 10, 14)                                                     # nz, ny, nx
+    rho = (1.2 + 0.1 * rng.random(n)).astype(np.float32)
+    sp, org = (100.0, 110.0, 120.0), (-500.0, -400.0, 300000.0)
+
+    def header(encoding, endian):
+        return (f"NRRD0005\ntype: float\ndimension: 3\nsizes: {n[2]} {n[1]} {n[0]}\nendian: {endian}\nencoding: {encoding}\n"
+                f"spacings: {sp[0]} {sp[1]} {sp[2]}\nspace origin: ({org[0]},{org[1]},{org[2]})\n\n").encode()
+    little, big = rho.astype("<f4").tobytes(), rho.astype(">f4").tobytes()
+    files = {"raw_little": header("raw", "little") + little, "raw_big": header("raw", "big") + big,
+             "gzip_little": header("gzip", "little") + gzip.compress(little), "gz_big": header("gz", "big") + gzip.compress(big),
+             "zlib_wrapped": header("gzip", "little") + zlib.compress(little),
+             "ascii": header("ascii", "little") + " ".join(repr(float(v)) for v in rho.ravel()).encode() + b"\n",
+             "text_lines": header("text", "little") + "\n".join(repr(float(v)) for v in rho.ravel()).encode()}
+    want = None
+    for name, blob in files.items():
+        path = tmp_path / f"{name}.nrrd"
+        path.write_bytes(blob)
+        v = photon.volume_load_nrrd(str(path), 1)
+        tex = v.download()
+        v.free()
+        if want is None:
+            want = tex
+            o = oracle.volume_from_density(rho, sp, org, 1)
+            assert_bit_equal(tex, o.download(), "raw file vs the oracle's build of the same array")
+            o.free()
+        assert_bit_equal(tex, want, name)
+    L = photon.lib
+    gz = gzip.compress(little)
+    bad = {"truncated": header("gzip", "little") + gz[:len(gz) // 2], "garbage": header("gzip", "little") + b"\x1f\x8b" + b"\0" * 64,
+           "short": header("gzip", "little") + gzip.compress(little[:-400]),
+           "sizes_lie": header("gzip", "little").replace(f"sizes: {n[2]} {n[1]} {n[0]}".encode(), b"sizes: 60000 60000 60000") + gz,
+           "ascii_short": header("ascii", "little") + b"1.0 2.0 3.0\n", "unknown": header("bzip2", "little") + little,
+           "endian": header("raw", "middle") + little}
+    for name, blob in bad.items():
+        path = tmp_path / f"bad_{name}.nrrd"
+        path.write_bytes(blob)
+        h = ctypes.c_void_p()
+        assert L.photon_volume_load_nrrd(str(path).encode(), 1, ctypes.byref(h)) != 0 and not h.value, name
+
+
 def test_normal_range_division_and_sqrt_are_exact(photon):
     """The march loops divide and take square roots with the compiler's correctly rounded sequences MINUS their range scaling
     (device_vec.hpp, div_nr / rcp_nr / sqrt_nr: 16 instructions fewer per RK4 iteration).  Same instructions on the same
